@@ -1,0 +1,46 @@
+/*
+ * rtu_oracle.h — C interface of the CPU restatement (oracle/rtu_oracle.cpp).
+ * TEST INFRASTRUCTURE: see the header of rtu_oracle.cpp. Loaded only by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ */
+#ifndef RTU_ORACLE_H_INCLUDED
+#define RTU_ORACLE_H_INCLUDED
+
+#include "rtu_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTU_ORACLE_ERR_ARG         (-1)
+#define RTU_ORACLE_ERR_STOCHASTIC  (-2) /* soft shadows / glossy / dof: reference is non-deterministic */
+#define RTU_ORACLE_ERR_UNSUPPORTED (-3) /* textures etc.: outside the restated scope */
+
+/* Same fields, same meaning as RtuStats in rtu_render.h, so CPU and GPU ray and
+ * traversal counters can be compared exactly. */
+typedef struct RtuOracleStats {
+    uint64_t primary_rays, primary_hits;
+    uint64_t secondary_rays;  /* root-level Trace calls issued by Shade */
+    uint64_t shadow_rays;     /* root-level ShadowTrace calls issued by Shadow */
+    uint64_t node_tests;      /* ray x object-node intersection calls */
+    uint64_t mesh_entries;    /* rays that passed a mesh's bounding box */
+    uint64_t inner_visits, leaf_visits, leaf_elems;
+    uint64_t tri_tests, tri_accepts;
+} RtuOracleStats;
+
+/* Recipe W over rows [row0,row0+nrows): rgbz_out holds nrows*width float4
+ * {linear r,g,b, z}; z = hInfo.z of the primary hit (RTU_BIGFLOAT on a miss). */
+int  rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int row0, int nrows,
+                            float* rgbz_out, RtuOracleStats* stats, int threads);
+int  rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* rgbz_out,
+                       RtuOracleStats* stats, int threads);
+/* pos, origin, u, v of the image plane (RenderFunctions.cpp:243-269). */
+int  rtu_oracle_camera_frame(const RtuCamera* cam, int width, int height, float out12[12]);
+/* gamma + Color24 + z-image; any output pointer may be NULL. */
+void rtu_oracle_postprocess(const float* rgbz, int width, int height, unsigned char* rgb_out,
+                            float* z_out, unsigned char* zimg_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,44 @@
+// host_internal.h — shared declarations of librtu_host.so's translation units.
+#ifndef RTU_HOST_INTERNAL_H
+#define RTU_HOST_INTERNAL_H
+
+#include "rtu_host.h"
+
+#include <string>
+#include <vector>
+
+namespace rtu {
+
+void set_error(const std::string& msg);
+
+struct MeshData {
+    std::vector<float>      v, vn, vt;
+    std::vector<uint32_t>   f, fn, ft;
+    std::vector<RtuBvhNode> bvh;
+    std::vector<uint32_t>   elements;
+    uint32_t bvh_depth = 0;
+    float    bound_min[3] = {1, 1, 1};   // cyTriMesh.h:128 "not ready" box
+    float    bound_max[3] = {0, 0, 0};
+};
+
+// An owned flattened scene; `desc` always points into the vectors below.
+struct Scene {
+    std::vector<RtuNode>     nodes;
+    std::vector<RtuMaterial> materials;
+    std::vector<RtuLight>    lights;
+    std::vector<MeshData>    meshes;
+    std::vector<RtuMesh>     mesh_descs;
+    RtuCamera   camera{};
+    RtuEnvColor background{};
+    RtuEnvColor environment{};
+    RtuSceneDesc desc{};
+
+    static Scene* from_desc(const RtuSceneDesc& d);
+    void rebuild_desc();
+};
+
+}  // namespace rtu
+
+extern "C" RtuScene* rtu_scene_wrap(rtu::Scene* s);
+
+#endif

@@ -1,0 +1,124 @@
+/*
+ * rtu_render.h — the C-ABI of librtu_hip.so: the MI355X (gfx950) render path.
+ *
+ * This is the drop-in boundary behind the reference's BeginRender()
+ * (main.cpp:66-68 -> SpawnRenderThreads main.cpp:29-64 -> Render
+ * RenderFunctions.cpp:55-176). The host keeps the reference's scene graph /
+ * RenderImage surface (see rtu_host.h) and calls, per frame:
+ *
+ *   rtu_create_context      once per GPU                    [no reference counterpart]
+ *   rtu_upload_scene        <- the globals LoadScene fills  xmlload.cpp:64-131, main.cpp:17-27
+ *   rtu_frame_setup         <- CalculateImageOrigin /       RenderFunctions.cpp:243-269
+ *                              CalculateCurrentPoint (hoisted: origin,u,v)
+ *   rtu_render_frame[_device] <- the per-pixel loop         RenderFunctions.cpp:62-174 with
+ *                              PixelIterator::GetPixelLocation (PixelIterator.h:25-38),
+ *                              Trace/ShadowTrace (RenderFunctions.cpp:181-240),
+ *                              Object::IntersectRay (objFunctions.cpp:15-522),
+ *                              MtlBlinn::Shade (mtlFunctions.cpp:120-298),
+ *                              Light::Illuminate (lightFunctions.cpp:27-84, lights.h:32,48)
+ *   rtu_destroy_context
+ *
+ * Output is linear float4 {r,g,b,z} per pixel (z = hInfo.z of the primary hit,
+ * RTU_BIGFLOAT on a miss); gamma / Color24 / z-image stay on the host
+ * (rtu_host.h) as in RenderFunctions.cpp:155-159 and scene.h:590-612.
+ *
+ * Plain pointers and sizes only; never throws; returns 0 or a negative RTU_ERR_*.
+ * A context is single-caller. The caller owns host buffers; the library owns
+ * its device buffers (scene, counters, recursion arena, default framebuffer).
+ */
+#ifndef RTU_RENDER_H_INCLUDED
+#define RTU_RENDER_H_INCLUDED
+
+#include "rtu_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTU_OK               0
+#define RTU_ERR_ARG         (-1)  /* NULL / out-of-range argument */
+#define RTU_ERR_HIP         (-2)  /* a HIP runtime call failed (see rtu_last_error) */
+#define RTU_ERR_UNSUPPORTED (-3)  /* scene exceeds a device-path limit or uses textures */
+#define RTU_ERR_STOCHASTIC  (-4)  /* soft shadows / glossy bounces / depth of field */
+#define RTU_ERR_NO_SCENE    (-5)  /* render before rtu_upload_scene */
+#define RTU_ERR_NO_DEVICE   (-6)  /* no such GPU */
+
+#define RTU_BAND_ROWS 8  /* image rows per band; one wavefront renders an 8x8 pixel tile */
+
+typedef struct RtuContext RtuContext;
+
+/* One frame. Bands of RTU_BAND_ROWS rows are dealt round-robin to shards:
+ * band b belongs to shard (b % shard_count); a context renders only its shard
+ * and writes it COMPACTLY (local row lr -> global row rtu_shard_global_row). */
+typedef struct RtuFrameDesc {
+    int32_t width, height;
+    int32_t shard_rank, shard_count;  /* 0,1 for a single GPU */
+    int32_t max_bounce;               /* 5, RenderFunctions.cpp:134 */
+    int32_t collect_stats;            /* 1: fill the ray / traversal counters (slower kernel variant) */
+    int32_t reserved[2];
+    float   cam_pos[3];               /* camera.pos */
+    float   origin[3];                /* CalculateImageOrigin(camera.focaldist) */
+    float   u[3], v[3];               /* per-pixel steps of CalculateCurrentPoint */
+} RtuFrameDesc;
+
+/* Ray and traversal counters of one frame (all shards of one context). Same
+ * fields as RtuOracleStats so CPU and GPU can be compared exactly. */
+typedef struct RtuStats {
+    uint64_t primary_rays, primary_hits;
+    uint64_t secondary_rays;  /* root-level Trace calls issued by Shade */
+    uint64_t shadow_rays;     /* root-level ShadowTrace calls issued by Shadow */
+    uint64_t node_tests;      /* ray x object-node intersection calls */
+    uint64_t mesh_entries;    /* rays that passed a mesh's bounding box */
+    uint64_t inner_visits, leaf_visits, leaf_elems;
+    uint64_t tri_tests, tri_accepts;
+} RtuStats;
+
+int         rtu_device_count(void);
+const char* rtu_error_string(int err);
+
+RtuContext* rtu_create_context(int device_id, int* err_out);
+void        rtu_destroy_context(RtuContext* ctx);
+const char* rtu_last_error(const RtuContext* ctx);
+
+/* Validate, flatten into the device layout and copy to HBM. May be called again
+ * to replace the scene. */
+int  rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* scene);
+
+/* Fill width/height, cam_pos/origin/u/v from the camera (fp64 tan chain of
+ * RenderFunctions.cpp:247 evaluated on the host, once per frame), single shard,
+ * max_bounce 5, no stats. Pure host arithmetic; needs no GPU. */
+int  rtu_frame_setup(const RtuCamera* camera, int width, int height, RtuFrameDesc* frame_out);
+
+/* Shard geometry helpers (pure arithmetic). */
+int  rtu_shard_rows(const RtuFrameDesc* frame);                    /* rows this shard renders */
+int  rtu_shard_max_rows(int height, int shard_count);             /* max over ranks (gather padding) */
+int  rtu_shard_global_row(const RtuFrameDesc* frame, int local_row);
+
+/* Render this context's shard into DEVICE memory d_rgbz (rtu_shard_rows * width
+ * float4, 16-byte aligned), asynchronously on hip_stream (a hipStream_t passed
+ * as void*; NULL = the context's own stream). Inputs are already resident in
+ * HBM; nothing is copied. */
+int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream);
+
+/* Render into the context's own framebuffer and copy the shard to host memory
+ * h_rgbz (rtu_shard_rows * width * 4 floats). Synchronous. stats may be NULL. */
+int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, RtuStats* stats);
+
+/* Counters of the last frame rendered with collect_stats=1 (synchronises). */
+int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
+
+/* Measurement helper for bench.py: launch the render kernel `iters` times
+ * back-to-back on `hip_stream`, bracketed by HIP events recorded on that same
+ * stream, and return the AVERAGE kernel duration in milliseconds. */
+int  rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream,
+                     int iters, float* avg_ms_out);
+
+/* Device memory helpers so a C/C++ host needs no HIP headers. */
+void* rtu_device_alloc(RtuContext* ctx, size_t bytes);
+void  rtu_device_free(RtuContext* ctx, void* d_ptr);
+int   rtu_copy_to_host(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTU_RENDER_H_INCLUDED */

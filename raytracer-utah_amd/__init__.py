@@ -1,0 +1,365 @@
+"""raytracer-utah_amd — MI355X-native render hot path for RayTracer-Utah scenes.
+
+Python here is plumbing only (tests, bench.py, torch.distributed glue): a ctypes
+view of the two product libraries
+
+  lib/librtu_hip.so   C-ABI of include/rtu_render.h  (hand-written gfx950 HIP kernels)
+  lib/librtu_host.so  C entry points of include/rtu_host.h (scene loader, flattener,
+                      RenderImage mirror, PNG, BeginRender)
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded the
+import fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C raytracer-utah_amd`). The CPU oracle lives under oracle/ and is test
+infrastructure; nothing in this package touches it.
+
+The directory name contains a hyphen, so it is imported by path as module
+`raytracer_utah_amd` (see __graft_entry__.load_package()).
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_PKG, "lib")
+
+RTU_BIGFLOAT = 1.0e30
+RTU_BAND_ROWS = 8
+
+RTU_OK = 0
+RTU_ERR_ARG = -1
+RTU_ERR_HIP = -2
+RTU_ERR_UNSUPPORTED = -3
+RTU_ERR_STOCHASTIC = -4
+RTU_ERR_NO_SCENE = -5
+RTU_ERR_NO_DEVICE = -6
+
+
+class RtuError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("rtu error %d: %s" % (code, msg))
+
+
+class RtuCamera(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_float * 3), ("dir", ctypes.c_float * 3), ("up", ctypes.c_float * 3),
+                ("fov", ctypes.c_float), ("focaldist", ctypes.c_float), ("dof", ctypes.c_float),
+                ("img_width", ctypes.c_int32), ("img_height", ctypes.c_int32)]
+
+
+class RtuEnvColor(ctypes.Structure):
+    _fields_ = [("color", ctypes.c_float * 3), ("has_map", ctypes.c_int32), ("map_is_null", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 3)]
+
+
+class RtuSceneDesc(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_uint32), ("n_materials", ctypes.c_uint32), ("n_lights", ctypes.c_uint32),
+                ("n_meshes", ctypes.c_uint32), ("nodes", ctypes.c_void_p), ("materials", ctypes.c_void_p),
+                ("lights", ctypes.c_void_p), ("meshes", ctypes.c_void_p), ("camera", RtuCamera),
+                ("background", RtuEnvColor), ("environment", RtuEnvColor)]
+
+
+class RtuFrameDesc(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("shard_rank", ctypes.c_int32),
+                ("shard_count", ctypes.c_int32), ("max_bounce", ctypes.c_int32), ("collect_stats", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2), ("cam_pos", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
+                ("u", ctypes.c_float * 3), ("v", ctypes.c_float * 3)]
+
+
+STAT_FIELDS = ("primary_rays", "primary_hits", "secondary_rays", "shadow_rays", "node_tests", "mesh_entries",
+               "inner_visits", "leaf_visits", "leaf_elems", "tri_tests", "tri_accepts")
+
+
+class RtuStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in STAT_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+
+
+def algorithmic_bytes(stats, pixels):
+    """cache-agnostic bytes the path touches for one frame."""
+    s = stats if isinstance(stats, dict) else stats.as_dict()
+    return (56 * s["inner_visits"] + 4 * s["leaf_elems"] + 48 * s["tri_tests"] + 96 * s["tri_accepts"]
+            + 72 * s["node_tests"] + 16 * pixels)
+
+
+def total_rays(stats):
+    s = stats if isinstance(stats, dict) else stats.as_dict()
+    return s["primary_rays"] + s["secondary_rays"] + s["shadow_rays"]
+
+
+def _load(name):
+    path = os.path.join(_LIB, name)
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: build the HIP extension first (__graft_entry__.build() or "
+                          "`make -C raytracer-utah_amd`); there is no CPU fallback" % path)
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+hip = _load("librtu_hip.so")
+host = _load("librtu_host.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+
+def _sig(lib, name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# ---- rtu_render.h ----------------------------------------------------------
+HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
+               "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_get_stats", "rtu_time_render", "rtu_device_alloc",
+               "rtu_device_free", "rtu_copy_to_host"]
+_sig(hip, "rtu_device_count", _I)
+_sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
+_sig(hip, "rtu_create_context", _P, _I, ctypes.POINTER(_I))
+_sig(hip, "rtu_destroy_context", None, _P)
+_sig(hip, "rtu_last_error", ctypes.c_char_p, _P)
+_sig(hip, "rtu_upload_scene", _I, _P, _P)
+_sig(hip, "rtu_frame_setup", _I, ctypes.POINTER(RtuCamera), _I, _I, ctypes.POINTER(RtuFrameDesc))
+_sig(hip, "rtu_shard_rows", _I, ctypes.POINTER(RtuFrameDesc))
+_sig(hip, "rtu_shard_max_rows", _I, _I, _I)
+_sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
+_sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
+_sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
+_sig(hip, "rtu_get_stats", _I, _P, ctypes.POINTER(RtuStats))
+_sig(hip, "rtu_time_render", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P, _I, ctypes.POINTER(ctypes.c_float))
+_sig(hip, "rtu_device_alloc", _P, _P, ctypes.c_size_t)
+_sig(hip, "rtu_device_free", None, _P, _P)
+_sig(hip, "rtu_copy_to_host", _I, _P, _P, _P, ctypes.c_size_t)
+
+# ---- rtu_host.h --------------------------------------------------------------
+HOST_SYMBOLS = ["rtu_scene_load_xml", "rtu_scene_clone", "rtu_scene_load_blob", "rtu_scene_load_blob_file",
+                "rtu_scene_to_blob", "rtu_scene_save_blob_file", "rtu_blob_free", "rtu_scene_desc",
+                "rtu_scene_set_resolution", "rtu_scene_free", "rtu_host_last_error", "rtu_image_create",
+                "rtu_image_free", "rtu_image_width", "rtu_image_height", "rtu_image_pixels", "rtu_image_zbuffer",
+                "rtu_image_zimage", "rtu_image_num_rendered", "rtu_image_is_done", "rtu_image_from_rgbz",
+                "rtu_image_compute_zimg", "rtu_image_save_png", "rtu_image_save_zpng", "rtu_write_png",
+                "rtu_begin_render", "rtu_stop_render", "rtu_render_wait", "rtu_render_job_free"]
+_sig(host, "rtu_scene_load_xml", _P, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
+_sig(host, "rtu_scene_clone", _P, _P)
+_sig(host, "rtu_scene_load_blob", _P, _P, ctypes.c_size_t)
+_sig(host, "rtu_scene_load_blob_file", _P, ctypes.c_char_p)
+_sig(host, "rtu_scene_to_blob", _P, _P, ctypes.POINTER(ctypes.c_size_t))
+_sig(host, "rtu_scene_save_blob_file", _I, _P, ctypes.c_char_p)
+_sig(host, "rtu_blob_free", None, _P)
+_sig(host, "rtu_scene_desc", ctypes.POINTER(RtuSceneDesc), _P)
+_sig(host, "rtu_scene_set_resolution", None, _P, _I, _I)
+_sig(host, "rtu_scene_free", None, _P)
+_sig(host, "rtu_host_last_error", ctypes.c_char_p)
+_sig(host, "rtu_image_create", _P, _I, _I)
+_sig(host, "rtu_image_free", None, _P)
+_sig(host, "rtu_image_width", _I, _P)
+_sig(host, "rtu_image_height", _I, _P)
+_sig(host, "rtu_image_pixels", _P, _P)
+_sig(host, "rtu_image_zbuffer", _P, _P)
+_sig(host, "rtu_image_zimage", _P, _P)
+_sig(host, "rtu_image_num_rendered", _I, _P)
+_sig(host, "rtu_image_is_done", _I, _P)
+_sig(host, "rtu_image_from_rgbz", None, _P, _P, _I, _I)
+_sig(host, "rtu_image_compute_zimg", None, _P)
+_sig(host, "rtu_image_save_png", _I, _P, ctypes.c_char_p)
+_sig(host, "rtu_image_save_zpng", _I, _P, ctypes.c_char_p)
+_sig(host, "rtu_write_png", _I, ctypes.c_char_p, _P, _I, _I, _I)
+_sig(host, "rtu_begin_render", _P, _P, _P, ctypes.POINTER(_I), _I, ctypes.c_char_p, ctypes.c_char_p)
+_sig(host, "rtu_stop_render", None, _P)
+_sig(host, "rtu_render_wait", _I, _P)
+_sig(host, "rtu_render_job_free", None, _P)
+
+
+class Scene:
+    """Owned flattened scene (RtuScene*)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RtuError(RTU_ERR_ARG, host.rtu_host_last_error().decode())
+        self._h = handle
+
+    @classmethod
+    def from_xml(cls, path, remap_from=None, remap_to=None):
+        enc = lambda s: s.encode() if s is not None else None
+        return cls(host.rtu_scene_load_xml(path.encode(), enc(remap_from), enc(remap_to)))
+
+    @classmethod
+    def from_blob_bytes(cls, data):
+        buf = ctypes.create_string_buffer(data, len(data))
+        return cls(host.rtu_scene_load_blob(ctypes.cast(buf, _P), len(data)))
+
+    @classmethod
+    def from_blob_file(cls, path):
+        if path.endswith(".gz"):
+            import gzip
+            with gzip.open(path, "rb") as f:
+                return cls.from_blob_bytes(f.read())
+        return cls(host.rtu_scene_load_blob_file(path.encode()))
+
+    def to_blob_bytes(self):
+        n = ctypes.c_size_t(0)
+        p = host.rtu_scene_to_blob(self.desc_ptr, ctypes.byref(n))
+        if not p:
+            raise RtuError(RTU_ERR_ARG, "serialisation failed")
+        try:
+            return ctypes.string_at(p, n.value)
+        finally:
+            host.rtu_blob_free(p)
+
+    @property
+    def desc(self):
+        return host.rtu_scene_desc(self._h).contents
+
+    @property
+    def desc_ptr(self):
+        return ctypes.cast(host.rtu_scene_desc(self._h), _P)
+
+    def set_resolution(self, w, h):
+        host.rtu_scene_set_resolution(self._h, w, h)
+
+    def close(self):
+        if self._h:
+            host.rtu_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stats=False, max_bounce=5):
+    f = RtuFrameDesc()
+    rc = hip.rtu_frame_setup(ctypes.byref(camera), width, height, ctypes.byref(f))
+    if rc != RTU_OK:
+        raise RtuError(rc, "rtu_frame_setup")
+    f.shard_rank, f.shard_count = shard_rank, shard_count
+    f.collect_stats = 1 if collect_stats else 0
+    f.max_bounce = max_bounce
+    return f
+
+
+class Context:
+    """One GPU (RtuContext*)."""
+
+    def __init__(self, device_id=0):
+        err = _I(0)
+        self._h = hip.rtu_create_context(device_id, ctypes.byref(err))
+        if not self._h:
+            raise RtuError(err.value, hip.rtu_error_string(err.value).decode())
+
+    def _check(self, rc):
+        if rc != RTU_OK:
+            raise RtuError(rc, hip.rtu_last_error(self._h).decode())
+
+    def upload(self, scene):
+        self._check(hip.rtu_upload_scene(self._h, scene.desc_ptr))
+
+    def render(self, frame, stats=False):
+        """Render this shard; returns (rgbz float32 [rows, W, 4], stats dict or None)."""
+        import numpy as np
+        rows = hip.rtu_shard_rows(ctypes.byref(frame))
+        out = np.empty((rows, frame.width, 4), np.float32)
+        st = RtuStats() if stats else None
+        self._check(hip.rtu_render_frame(self._h, ctypes.byref(frame), out.ctypes.data,
+                                         ctypes.byref(st) if stats else None))
+        return out, (st.as_dict() if stats else None)
+
+    def render_device(self, frame, d_ptr, stream=None):
+        self._check(hip.rtu_render_frame_device(self._h, ctypes.byref(frame), d_ptr, stream))
+
+    def time_render(self, frame, d_ptr, stream, iters):
+        ms = ctypes.c_float(0)
+        self._check(hip.rtu_time_render(self._h, ctypes.byref(frame), d_ptr, stream, iters, ctypes.byref(ms)))
+        return ms.value
+
+    def stats(self):
+        st = RtuStats()
+        self._check(hip.rtu_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            hip.rtu_destroy_context(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_rows(frame):
+    return hip.rtu_shard_rows(ctypes.byref(frame))
+
+
+def shard_global_rows(frame):
+    """Global row index of every local row of this shard."""
+    import numpy as np
+    n = shard_rows(frame)
+    return np.array([hip.rtu_shard_global_row(ctypes.byref(frame), i) for i in range(n)], dtype=np.int64)
+
+
+def assemble(shards, frames, height):
+    """De-interleave per-shard compact buffers into one [H, W, 4] image."""
+    import numpy as np
+    w = frames[0].width
+    out = np.empty((height, w, 4), np.float32)
+    for buf, fr in zip(shards, frames):
+        rows = shard_global_rows(fr)
+        out[rows] = buf[:len(rows)]
+    return out
+
+
+class Image:
+    """RenderImage mirror (RtuImage*): Color24 pixels, float z-buffer, z-image."""
+
+    def __init__(self, width, height):
+        self._h = host.rtu_image_create(width, height)
+        self.width, self.height = width, height
+
+    def fill(self, rgbz, row0=0):
+        import numpy as np
+        a = np.ascontiguousarray(rgbz, dtype=np.float32)
+        host.rtu_image_from_rgbz(self._h, a.ctypes.data, row0, a.shape[0])
+
+    def compute_zimage(self):
+        host.rtu_image_compute_zimg(self._h)
+
+    def pixels(self):
+        import numpy as np
+        p = host.rtu_image_pixels(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)),
+                                     (self.height, self.width, 3)).copy()
+
+    def zbuffer(self):
+        import numpy as np
+        p = host.rtu_image_zbuffer(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), (self.height, self.width)).copy()
+
+    def zimage(self):
+        import numpy as np
+        p = host.rtu_image_zimage(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (self.height, self.width)).copy()
+
+    def save(self, result_png=None, zbuffer_png=None):
+        if result_png and host.rtu_image_save_png(self._h, result_png.encode()) != 0:
+            raise RtuError(RTU_ERR_ARG, "cannot write " + result_png)
+        if zbuffer_png and host.rtu_image_save_zpng(self._h, zbuffer_png.encode()) != 0:
+            raise RtuError(RTU_ERR_ARG, "cannot write " + zbuffer_png)
+
+    def close(self):
+        if self._h:
+            host.rtu_image_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

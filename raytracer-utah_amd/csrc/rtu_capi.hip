@@ -1,0 +1,461 @@
+// rtu_capi.hip — host side of the C-ABI in include/rtu_render.h: context, scene
+// validation + upload into the HBM layout of rtu_device.h, frame set-up and
+// kernel launch. Compiled by hipcc with -ffp-contract=off so the few host-side
+// float computations (triangle normals, camera frame) round exactly like the
+// reference's CPU code.
+#include "rtu_device.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct RtuContext {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    std::string error;
+
+    // scene
+    bool     has_scene = false;
+    std::vector<void*> scene_allocs;
+    DevScene dscene{};
+    uint32_t bvh_stack_needed = 1;
+
+    // per-frame resources (grown on demand, reused)
+    float*  arena = nullptr;
+    size_t  arena_bytes = 0;
+    float4* fb = nullptr;
+    size_t  fb_bytes = 0;
+    unsigned long long* counters = nullptr;  // 11 x u64
+};
+
+namespace {
+
+int fail(RtuContext* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    return code;
+}
+
+#define RTU_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, RTU_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void free_scene(RtuContext* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+}
+
+template <class T>
+int upload(RtuContext* ctx, const T* src, size_t count, const T** dst) {
+    *dst = nullptr;
+    size_t bytes = sizeof(T) * count;
+    if (bytes == 0) bytes = 16;  // keep pointers valid for empty arrays
+    void* d = nullptr;
+    RTU_HIP(ctx, hipMalloc(&d, bytes));
+    ctx->scene_allocs.push_back(d);
+    if (count) RTU_HIP(ctx, hipMemcpy(d, src, sizeof(T) * count, hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(d);
+    return RTU_OK;
+}
+
+// Reject anything the kernel's indexing does not expect, so that a malformed
+// scene is an error code and never an out-of-bounds access on the GPU.
+int validate(RtuContext* ctx, const RtuSceneDesc* s) {
+    if (!s || !s->nodes || s->n_nodes == 0) return fail(ctx, RTU_ERR_ARG, "scene has no nodes");
+    if (s->n_materials && !s->materials) return fail(ctx, RTU_ERR_ARG, "materials is NULL");
+    if (s->n_lights && !s->lights) return fail(ctx, RTU_ERR_ARG, "lights is NULL");
+    if (s->n_meshes && !s->meshes) return fail(ctx, RTU_ERR_ARG, "meshes is NULL");
+    if (s->n_materials >= (1u << 20)) return fail(ctx, RTU_ERR_UNSUPPORTED, "too many materials");
+    if (s->camera.dof != 0) return fail(ctx, RTU_ERR_STOCHASTIC, "depth of field is stochastic");
+    if ((s->background.has_map && !s->background.map_is_null) || (s->environment.has_map && !s->environment.map_is_null))
+        return fail(ctx, RTU_ERR_UNSUPPORTED, "textured background/environment");
+    for (uint32_t i = 0; i < s->n_lights; i++) {
+        const RtuLight& l = s->lights[i];
+        if (l.type < RTU_LIGHT_AMBIENT || l.type > RTU_LIGHT_POINT) return fail(ctx, RTU_ERR_ARG, "light %u: bad type", i);
+        if (l.type == RTU_LIGHT_POINT && l.size > 0) return fail(ctx, RTU_ERR_STOCHASTIC, "light %u: soft shadow", i);
+    }
+    for (uint32_t i = 0; i < s->n_materials; i++)
+        if (s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0)
+            return fail(ctx, RTU_ERR_STOCHASTIC, "material %u: glossy bounce", i);
+    for (uint32_t i = 0; i < s->n_nodes; i++) {
+        const RtuNode& n = s->nodes[i];
+        if (i == 0 ? n.parent != -1 : (n.parent < 0 || (uint32_t)n.parent >= i))
+            return fail(ctx, RTU_ERR_ARG, "node %u: parent %d breaks pre-order", i, n.parent);
+        int depth = i == 0 ? 0 : s->nodes[n.parent].depth + 1;
+        if (n.depth != depth) return fail(ctx, RTU_ERR_ARG, "node %u: depth %d != %d", i, n.depth, depth);
+        if (depth >= RTU_MAX_NODE_DEPTH) return fail(ctx, RTU_ERR_UNSUPPORTED, "node %u deeper than %d", i, RTU_MAX_NODE_DEPTH - 1);
+        if (n.obj_type < RTU_OBJ_NONE || n.obj_type > RTU_OBJ_TRIMESH) return fail(ctx, RTU_ERR_ARG, "node %u: bad type", i);
+        if (n.obj_type == RTU_OBJ_TRIMESH && (n.mesh_id < 0 || (uint32_t)n.mesh_id >= s->n_meshes))
+            return fail(ctx, RTU_ERR_ARG, "node %u: bad mesh id", i);
+        if (n.material_id >= (int)s->n_materials) return fail(ctx, RTU_ERR_ARG, "node %u: bad material id", i);
+    }
+    for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
+        const RtuMesh& m = s->meshes[mi];
+        if (!m.v || !m.f || !m.vn || !m.fn || !m.bvh || !m.elements)
+            return fail(ctx, RTU_ERR_ARG, "mesh %u: missing array (normals are required, objects.h:56)", mi);
+        if (m.n_bvh_nodes < 2 || m.n_elements != m.nf || m.nf == 0) return fail(ctx, RTU_ERR_ARG, "mesh %u: empty", mi);
+        if (m.bvh_depth > RTU_MAX_BVH_STACK) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: BVH depth %u > %d", mi, m.bvh_depth, RTU_MAX_BVH_STACK);
+        for (uint32_t i = 0; i < m.nf * 3; i++) {
+            if (m.f[i] >= m.nv) return fail(ctx, RTU_ERR_ARG, "mesh %u: vertex index out of range", mi);
+            if (m.fn[i] >= m.nvn) return fail(ctx, RTU_ERR_ARG, "mesh %u: normal index out of range", mi);
+        }
+        for (uint32_t i = 0; i < m.n_elements; i++)
+            if (m.elements[i] >= m.nf) return fail(ctx, RTU_ERR_ARG, "mesh %u: element out of range", mi);
+        // every node reachable from the root must be well formed; children have larger
+        // ids than their parent (cyBVH.h:242-251), which also rules out cycles
+        std::vector<std::pair<uint32_t, uint32_t>> st;  // node, level
+        st.push_back({1u, 1u});
+        uint32_t depth = 0;
+        while (!st.empty()) {
+            auto [id, lvl] = st.back();
+            st.pop_back();
+            if (lvl > depth) depth = lvl;
+            const RtuBvhNode& n = m.bvh[id];
+            if (n.count == 0) {
+                if (n.index <= id || n.index + 1 >= m.n_bvh_nodes) return fail(ctx, RTU_ERR_ARG, "mesh %u: bad child index at node %u", mi, id);
+                st.push_back({n.index, lvl + 1});
+                st.push_back({n.index + 1, lvl + 1});
+            } else {
+                if (n.count > 8 || n.index + n.count > m.n_elements) return fail(ctx, RTU_ERR_ARG, "mesh %u: bad leaf at node %u", mi, id);
+            }
+        }
+        if (depth > m.bvh_depth) return fail(ctx, RTU_ERR_ARG, "mesh %u: bvh_depth %u understates the tree (%u)", mi, m.bvh_depth, depth);
+    }
+    return RTU_OK;
+}
+
+// background.Sample / environment.SampleEnvironment for the supported cases
+// (scene.h:421-431): untextured -> colour; TextureMap(NULL) -> colour * black.
+void env_value(const RtuEnvColor& e, float out[3]) {
+    for (int k = 0; k < 3; k++) out[k] = e.has_map ? e.color[k] * 0.0f : e.color[k];
+}
+
+int shard_bands(int height, int rank, int count) {
+    int nb = (height + RTU_BAND_ROWS - 1) / RTU_BAND_ROWS;
+    if (rank >= nb) return 0;
+    return (nb - rank + count - 1) / count;
+}
+
+int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
+    if (!f) return fail(ctx, RTU_ERR_ARG, "frame is NULL");
+    if (f->width <= 0 || f->height <= 0 || f->width > 65536 || f->height > 65536) return fail(ctx, RTU_ERR_ARG, "bad resolution");
+    if (f->shard_count < 1 || f->shard_rank < 0 || f->shard_rank >= f->shard_count) return fail(ctx, RTU_ERR_ARG, "bad shard");
+    if (f->max_bounce < 0 || f->max_bounce > RTU_MAX_BOUNCE) return fail(ctx, RTU_ERR_ARG, "max_bounce out of range");
+    return RTU_OK;
+}
+
+int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
+    uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
+    uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
+    uint32_t n_blocks = tiles_x * bands;
+    uint32_t n_threads = n_blocks * 64;
+    size_t need = (size_t)n_threads * RTU_FRAME_FIELDS * sizeof(float) * (size_t)(frame->max_bounce > 0 ? frame->max_bounce : 1);
+    if (need > ctx->arena_bytes) {
+        if (ctx->arena) (void)hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        RTU_HIP(ctx, hipMalloc((void**)&ctx->arena, need));
+        ctx->arena_bytes = need;
+    }
+    bool stats = frame->collect_stats != 0;
+    if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
+    KernelArgs a;
+    a.scene = ctx->dscene;
+    a.frame = *frame;
+    a.out = d_out;
+    a.arena = ctx->arena;
+    a.counters = stats ? ctx->counters : nullptr;
+    a.tiles_x = tiles_x;
+    a.n_threads = n_threads;
+    hipError_t e = (hipError_t)rtu_launch_render(a, n_blocks, ctx->bvh_stack_needed, stats, stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rtu_error_string(int err) {
+    switch (err) {
+        case RTU_OK: return "ok";
+        case RTU_ERR_ARG: return "invalid argument";
+        case RTU_ERR_HIP: return "HIP runtime error";
+        case RTU_ERR_UNSUPPORTED: return "scene outside the device path's limits";
+        case RTU_ERR_STOCHASTIC: return "scene uses a stochastic feature";
+        case RTU_ERR_NO_SCENE: return "no scene uploaded";
+        case RTU_ERR_NO_DEVICE: return "no such GPU";
+    }
+    return "unknown error";
+}
+
+RtuContext* rtu_create_context(int device_id, int* err_out) {
+    int n = rtu_device_count();
+    if (device_id < 0 || device_id >= n) {
+        if (err_out) *err_out = RTU_ERR_NO_DEVICE;
+        return nullptr;
+    }
+    RtuContext* ctx = new RtuContext;
+    ctx->device = device_id;
+    bool ok = hipSetDevice(device_id) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
+              hipMalloc((void**)&ctx->counters, 11 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(ctx->counters, 0, 11 * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        if (err_out) *err_out = RTU_ERR_HIP;
+        rtu_destroy_context(ctx);
+        return nullptr;
+    }
+    if (err_out) *err_out = RTU_OK;
+    return ctx;
+}
+
+void rtu_destroy_context(RtuContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->fb) (void)hipFree(ctx->fb);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rtu_last_error(const RtuContext* ctx) { return ctx ? ctx->error.c_str() : "context is NULL"; }
+
+int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
+    if (!ctx) return RTU_ERR_ARG;
+    int rc = validate(ctx, s);
+    if (rc != RTU_OK) return rc;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    // scene-graph nodes with their ancestor chains
+    std::vector<DevNode> nodes(s->n_nodes);
+    for (uint32_t i = 0; i < s->n_nodes; i++) {
+        const RtuNode& n = s->nodes[i];
+        DevNode& d = nodes[i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.tm, n.tm, sizeof d.tm);
+        memcpy(d.itm, n.itm, sizeof d.itm);
+        memcpy(d.pos, n.pos, sizeof d.pos);
+        d.parent = n.parent;
+        d.obj_type = n.obj_type;
+        d.mesh_id = n.mesh_id;
+        d.material_id = n.material_id;
+        d.depth = n.depth;
+        int j = (int)i;
+        for (int dd = n.depth; dd >= 0; dd--) {
+            d.chain[dd] = j;
+            j = s->nodes[j].parent;
+        }
+    }
+
+    // meshes
+    std::vector<DevMesh> meshes(s->n_meshes);
+    uint32_t stack_needed = 1;
+    for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
+        const RtuMesh& m = s->meshes[mi];
+        DevMesh& d = meshes[mi];
+        memset(&d, 0, sizeof d);
+        // triangle records in leaf order: {A,N.x | B,N.y | C,N.z}; N as objFunctions.cpp:263
+        std::vector<float4> tri((size_t)m.n_elements * 3);
+        for (uint32_t e = 0; e < m.n_elements; e++) {
+            const uint32_t* fv = m.f + 3 * m.elements[e];
+            f3 A = ld3(m.v + 3 * fv[0]), B = ld3(m.v + 3 * fv[1]), C = ld3(m.v + 3 * fv[2]);
+            f3 N = norm3(cross3(B - A, C - A));
+            tri[3 * e + 0] = make_float4(A.x, A.y, A.z, N.x);
+            tri[3 * e + 1] = make_float4(B.x, B.y, B.z, N.y);
+            tri[3 * e + 2] = make_float4(C.x, C.y, C.z, N.z);
+        }
+        static_assert(sizeof(RtuBvhNode) == 2 * sizeof(float4), "BVH node is two float4");
+        if ((rc = upload(ctx, reinterpret_cast<const float4*>(m.bvh), (size_t)m.n_bvh_nodes * 2, &d.bvh)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, tri.data(), tri.size(), &d.tri)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.elements, (size_t)m.n_elements, &d.elements)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.fn, (size_t)m.nf * 3, &d.fn)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.vn, (size_t)m.nvn * 3, &d.vn)) != RTU_OK) return rc;
+        memcpy(d.bmin, m.bound_min, sizeof d.bmin);
+        memcpy(d.bmax, m.bound_max, sizeof d.bmax);
+        d.n_bvh_nodes = m.n_bvh_nodes;
+        d.n_elements = m.n_elements;
+        if (m.bvh_depth > stack_needed) stack_needed = m.bvh_depth;
+    }
+
+    DevScene ds;
+    memset(&ds, 0, sizeof ds);
+    if ((rc = upload(ctx, nodes.data(), nodes.size(), &ds.nodes)) != RTU_OK) return rc;
+    if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &ds.materials)) != RTU_OK) return rc;
+    if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &ds.lights)) != RTU_OK) return rc;
+    if ((rc = upload(ctx, meshes.data(), meshes.size(), &ds.meshes)) != RTU_OK) return rc;
+    ds.n_nodes = s->n_nodes;
+    ds.n_lights = s->n_lights;
+    env_value(s->background, ds.background);
+    env_value(s->environment, ds.environment);
+    ctx->dscene = ds;
+    ctx->bvh_stack_needed = stack_needed;
+    ctx->has_scene = true;
+    return RTU_OK;
+}
+
+// CalculateImageOrigin + the u,v of CalculateCurrentPoint (RenderFunctions.cpp:243-269)
+int rtu_frame_setup(const RtuCamera* cam, int width, int height, RtuFrameDesc* out) {
+    if (!cam || !out || width <= 0 || height <= 0) return RTU_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->width = width;
+    out->height = height;
+    out->shard_rank = 0;
+    out->shard_count = 1;
+    out->max_bounce = RTU_MAX_BOUNCE;
+    out->collect_stats = 0;
+    f3 pos = ld3(cam->pos), dir = ld3(cam->dir), up = ld3(cam->up);
+    float distanceToImg = cam->focaldist;
+    float actualHeight = (float)(tan((cam->fov / 2) * M_PI / 180.0) * 2 * distanceToImg);  // :247
+    float actualWidth = ((float)width / (float)height) * actualHeight;                      // :248
+    f3 dirN = norm3(dir), upN = norm3(up);
+    f3 topCenterPoint = (pos + dirN * distanceToImg) + upN * (actualHeight / 2);            // :250
+    f3 right = norm3(cross3(dirN, upN));
+    f3 origin = topCenterPoint - right * (actualWidth / 2);                                 // :252
+    f3 u = right * (actualWidth / (float)width);                                            // :263
+    f3 v = (upN * -1.0f) * (actualHeight / (float)height);                                  // :264
+    out->cam_pos[0] = pos.x; out->cam_pos[1] = pos.y; out->cam_pos[2] = pos.z;
+    out->origin[0] = origin.x; out->origin[1] = origin.y; out->origin[2] = origin.z;
+    out->u[0] = u.x; out->u[1] = u.y; out->u[2] = u.z;
+    out->v[0] = v.x; out->v[1] = v.y; out->v[2] = v.z;
+    return RTU_OK;
+}
+
+int rtu_shard_rows(const RtuFrameDesc* f) {
+    if (!f || f->shard_count < 1 || f->shard_rank < 0 || f->shard_rank >= f->shard_count || f->height <= 0) return 0;
+    int bands = shard_bands(f->height, f->shard_rank, f->shard_count);
+    if (bands == 0) return 0;
+    int last_global_band = (bands - 1) * f->shard_count + f->shard_rank;
+    int rows = bands * RTU_BAND_ROWS;
+    int over = (last_global_band + 1) * RTU_BAND_ROWS - f->height;
+    if (over > 0) rows -= over;
+    return rows;
+}
+
+int rtu_shard_max_rows(int height, int shard_count) {
+    if (height <= 0 || shard_count < 1) return 0;
+    return shard_bands(height, 0, shard_count) * RTU_BAND_ROWS;
+}
+
+int rtu_shard_global_row(const RtuFrameDesc* f, int local_row) {
+    if (!f || local_row < 0) return -1;
+    int lb = local_row / RTU_BAND_ROWS;
+    return (lb * f->shard_count + f->shard_rank) * RTU_BAND_ROWS + local_row % RTU_BAND_ROWS;
+}
+
+int rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream) {
+    if (!ctx) return RTU_ERR_ARG;
+    int rc = check_frame(ctx, frame);
+    if (rc != RTU_OK) return rc;
+    if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
+    if (!d_rgbz && rtu_shard_rows(frame) > 0) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return launch(ctx, frame, (float4*)d_rgbz, st, true);
+}
+
+int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
+    if (!ctx || !stats) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    static_assert(sizeof(RtuStats) == 11 * sizeof(unsigned long long), "RtuStats layout");
+    RTU_HIP(ctx, hipMemcpy(stats, ctx->counters, sizeof(RtuStats), hipMemcpyDeviceToHost));
+    return RTU_OK;
+}
+
+int rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, RtuStats* stats) {
+    if (!ctx) return RTU_ERR_ARG;
+    int rc = check_frame(ctx, frame);
+    if (rc != RTU_OK) return rc;
+    if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
+    if (!h_rgbz) return fail(ctx, RTU_ERR_ARG, "h_rgbz is NULL");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    size_t rows = (size_t)rtu_shard_rows(frame);
+    size_t bytes = rows * (size_t)frame->width * sizeof(float4);
+    if (bytes > ctx->fb_bytes) {
+        if (ctx->fb) (void)hipFree(ctx->fb);
+        ctx->fb = nullptr;
+        ctx->fb_bytes = 0;
+        RTU_HIP(ctx, hipMalloc((void**)&ctx->fb, bytes));
+        ctx->fb_bytes = bytes;
+    }
+    RtuFrameDesc f = *frame;
+    if (stats) f.collect_stats = 1;
+    rc = launch(ctx, &f, ctx->fb, ctx->stream, true);
+    if (rc != RTU_OK) return rc;
+    if (bytes) RTU_HIP(ctx, hipMemcpyAsync(h_rgbz, ctx->fb, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) return rtu_get_stats(ctx, stats);
+    return RTU_OK;
+}
+
+int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream, int iters, float* avg_ms_out) {
+    if (!ctx || !avg_ms_out || iters < 1) return RTU_ERR_ARG;
+    int rc = check_frame(ctx, frame);
+    if (rc != RTU_OK) return rc;
+    if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
+    if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    RTU_HIP(ctx, hipEventRecord(ctx->ev0, st));
+    for (int i = 0; i < iters; i++) {
+        rc = launch(ctx, frame, (float4*)d_rgbz, st, i == 0);
+        if (rc != RTU_OK) return rc;
+    }
+    RTU_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    RTU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    RTU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms_out = ms / (float)iters;
+    return RTU_OK;
+}
+
+void* rtu_device_alloc(RtuContext* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+
+void rtu_device_free(RtuContext* ctx, void* d_ptr) {
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(d_ptr);
+}
+
+int rtu_copy_to_host(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || !h_dst || !d_src) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    RTU_HIP(ctx, hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return RTU_OK;
+}
+
+}  // extern "C"

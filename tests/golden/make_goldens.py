@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Authoring container only (needs /root/reference and oracle/_ref/ref_render, built
+by `make -C oracle`). For every BASELINE config it runs the reference's own
+Trace/Shade functions through oracle/ref_harness/driver.cpp ("recipe W",
+SURVEY.md §8c) and stores DATA only:
+
+  scene.rtus.gz   flattened scene (input), serialised from the reference's
+                  in-memory scene graph after LoadScene()
+  Result.png      written by the reference's RenderImage::SaveImage (lodepng)
+  ZBuffer.png     written by RenderImage::SaveZImage after ComputeZBufferImage
+  golden.npz      full float z + linear RGB for the small configs; for 1080p an
+                  every-8th-pixel subsample (z, rgb) plus the 8-bit images
+  meta.json       resolution, ray counters, sha256 of the full float z / rgb /
+                  8-bit buffers
+
+No reference source text is copied; the fixtures are inputs and outputs.
+"""
+import gzip, hashlib, json, os, shutil, subprocess, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+RUN = os.path.join(REPO, "oracle", "ref_harness", "run_ref.sh")
+
+CONFIGS = [
+    # tag, scene (relative to SceneFiles), W, H, keep full floats
+    ("p1_256", "Project1Example.xml", 256, 256, True),
+    ("p3s_800x600", "Project3Simple.xml", 800, 600, True),
+    ("p4_1080", "Project4.xml", 1920, 1080, False),
+    ("teapot2_1080", "Teapot/scene2.xml", 1920, 1080, False),
+    ("p11_1080", "Project11/scene.xml", 1920, 1080, False),
+    # small versions of the 1080p configs so CPU-only tests stay fast
+    ("p4_240x135", "Project4.xml", 240, 135, True),
+    ("teapot2_240x135", "Teapot/scene2.xml", 240, 135, True),
+    ("p11_240x135", "Project11/scene.xml", 240, 135, True),
+]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    for tag, scene, W, H, full in CONFIGS:
+        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"])
+        src = os.path.join(REPO, "oracle", "_ref", "out", tag)
+        dst = os.path.join(HERE, tag)
+        os.makedirs(dst, exist_ok=True)
+        with open(os.path.join(src, "scene.rtus"), "rb") as f, gzip.GzipFile(
+            os.path.join(dst, "scene.rtus.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+        for png in ("Result.png", "ZBuffer.png"):
+            shutil.copyfile(os.path.join(src, png), os.path.join(dst, png))
+        z = np.fromfile(os.path.join(src, "z.f32"), np.float32).reshape(H, W)
+        rgb = np.fromfile(os.path.join(src, "rgb.f32"), np.float32).reshape(H, W, 3)
+        res8 = np.fromfile(os.path.join(src, "result.u8"), np.uint8).reshape(H, W, 3)
+        z8 = np.fromfile(os.path.join(src, "zbuffer.u8"), np.uint8).reshape(H, W)
+        stats = json.load(open(os.path.join(src, "stats.json")))
+        meta = {
+            "scene": scene, "width": W, "height": H, "recipe": "W",
+            "primary": stats["primary"], "primary_hits": stats["primary_hits"],
+            "secondary": stats["secondary"], "shadow": stats["shadow"],
+            "sha256_z_f32": sha(z), "sha256_rgb_f32": sha(rgb),
+            "sha256_result_u8": sha(res8), "sha256_zbuffer_u8": sha(z8),
+            "sum_result_u8": int(res8.astype(np.uint64).sum()),
+            "sum_zbuffer_u8": int(z8.astype(np.uint64).sum()),
+            "nonzero_zbuffer_u8": int((z8 != 0).sum()),
+        }
+        arrays = {"result_u8": res8, "zbuffer_u8": z8}
+        if full:
+            arrays["z"] = z
+            arrays["rgb"] = rgb
+        else:
+            arrays["z_sub8"] = z[::8, ::8].copy()
+            arrays["rgb_sub8"] = rgb[::8, ::8].copy()
+        np.savez_compressed(os.path.join(dst, "golden.npz"), **arrays)
+        json.dump(meta, open(os.path.join(dst, "meta.json"), "w"), indent=1, sort_keys=True)
+        print(tag, meta["primary_hits"], meta["secondary"], meta["shadow"])
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,171 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU
+oracle on the same inputs and against the goldens generated from the compiled
+reference. Bars: float z bit-exact (hence ZBuffer.png exact), 8-bit RGB
+within +-1 per channel (device powf/expf vs glibc), ray / traversal counters equal."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import ALL_TAGS, FULL_TAGS, SMALL_TAGS, sha256
+
+pytestmark = pytest.mark.gpu
+
+RGB8_TOL = 1          # levels of 255, BASELINE.md "RGB +-1/255"
+RGB_REL_TOL = 2e-5    # linear float RGB: a few ulp through <=6 levels of powf/expf products
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def render_gpu(pkg, ctx, scene, W, H, stats=True, shard_count=1):
+    ctx.upload(scene)
+    shards, frames, allstats = [], [], None
+    for r in range(shard_count):
+        fr = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=r, shard_count=shard_count, collect_stats=stats)
+        buf, st = ctx.render(fr, stats=stats)
+        shards.append(buf)
+        frames.append(fr)
+        if stats:
+            allstats = st if allstats is None else {k: allstats[k] + st[k] for k in st}
+    return pkg.assemble(shards, frames, H), allstats
+
+
+def check_against(gpu, ref_rgbz, orc):
+    zbad = int((gpu[..., 3].view(np.uint32) != ref_rgbz[..., 3].view(np.uint32)).sum())
+    assert zbad == 0, "%d pixels differ in float z" % zbad
+    g8, _, gz8 = orc.postprocess(gpu)
+    c8, _, cz8 = orc.postprocess(ref_rgbz)
+    assert np.array_equal(gz8, cz8), "z-image differs"
+    d8 = np.abs(g8.astype(np.int32) - c8.astype(np.int32))
+    assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
+    a, b = gpu[..., :3].astype(np.float64), ref_rgbz[..., :3].astype(np.float64)
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    assert rel.max() <= RGB_REL_TOL, "linear RGB relative error %.3g" % rel.max()
+    return int((d8 > 0).sum())
+
+
+@pytest.mark.parametrize("tag", ALL_TAGS)
+def test_gpu_vs_oracle_and_golden(pkg, orc, ctx, golden, tag):
+    g = golden(tag)
+    scene = g.scene(pkg)
+    W, H = g.width, g.height
+    gpu, gstats = render_gpu(pkg, ctx, scene, W, H)
+    cpu, cstats = orc.render(scene, W, H, threads=8)
+    nflip = check_against(gpu, cpu, orc)
+    assert gstats == cstats, "counters differ"
+    # goldens from the compiled reference
+    assert sha256(gpu[..., 3]) == g.meta["sha256_z_f32"]
+    assert gstats["primary_hits"] == g.meta["primary_hits"]
+    assert gstats["secondary_rays"] == g.meta["secondary"]
+    assert gstats["shadow_rays"] == g.meta["shadow"]
+    g8, _, gz8 = orc.postprocess(gpu)
+    assert np.array_equal(gz8, g.npz["zbuffer_u8"]), "ZBuffer image differs from the reference's"
+    d = np.abs(g8.astype(np.int32) - g.npz["result_u8"].astype(np.int32))
+    assert d.max() <= RGB8_TOL
+    print("%s: %d/%d channel values off by one level" % (tag, nflip, W * H * 3))
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p4_240x135"])
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_sharded_render_is_identical(pkg, orc, ctx, golden, tag, shards):
+    """Band-interleaved shards assemble to exactly the single-GPU image (bit for bit,
+    RGB included: same kernel, same arithmetic), for every shard count."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    one, st1 = render_gpu(pkg, ctx, scene, g.width, g.height)
+    many, stn = render_gpu(pkg, ctx, scene, g.width, g.height, shard_count=shards)
+    assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+    assert st1 == stn
+
+
+def test_ragged_resolution(pkg, orc, ctx, golden):
+    """Width/height not multiples of the 8x8 tile, and a 1x1 image."""
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    for (W, H) in [(61, 45), (8, 8), (1, 1), (17, 3)]:
+        gpu, gst = render_gpu(pkg, ctx, scene, W, H)
+        cpu, cst = orc.render(scene, W, H, threads=2)
+        check_against(gpu, cpu, orc)
+        assert gst == cst
+
+
+def test_stats_variant_matches_fast_variant(pkg, ctx, golden):
+    g = golden("p4_240x135")
+    scene = g.scene(pkg)
+    a, _ = render_gpu(pkg, ctx, scene, g.width, g.height, stats=True)
+    b, _ = render_gpu(pkg, ctx, scene, g.width, g.height, stats=False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_device_render_and_timing_entry(pkg, ctx, golden):
+    """rtu_render_frame_device + rtu_time_render on a caller-owned device buffer."""
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    fr = pkg.frame_setup(scene.desc.camera, g.width, g.height)
+    nbytes = g.width * g.height * 16
+    d = pkg.hip.rtu_device_alloc(ctx._h, nbytes)
+    assert d
+    ms = ctx.time_render(fr, d, None, 3)
+    assert 0 < ms < 1000
+    out = np.empty((g.height, g.width, 4), np.float32)
+    assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, nbytes) == 0
+    ref, _ = ctx.render(fr)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    pkg.hip.rtu_device_free(ctx._h, d)
+
+
+def test_full_size_properties(pkg, ctx, golden):
+    """Size-independent properties at the BASELINE resolution: misses carry BIGFLOAT and
+    the background colour, hits have 0 < z < BIGFLOAT, re-rendering is idempotent."""
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    a, st = render_gpu(pkg, ctx, scene, g.width, g.height)
+    b, _ = render_gpu(pkg, ctx, scene, g.width, g.height)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    miss = a[..., 3] == np.float32(1e30)
+    assert int((~miss).sum()) == st["primary_hits"]
+    assert np.all(a[miss][:, :3] == 0)  # NULL-map background samples black
+    assert np.all(a[~miss][:, 3] > 0)
+    assert np.all(np.isfinite(a[..., :3]))
+
+
+def test_begin_render_dropin(pkg, orc, golden, tmp_path):
+    """BeginRender()-style asynchronous entry of the host library writes Result.png and
+    ZBuffer.png equal to the reference's decoded pixels (z exact, RGB +-1)."""
+    from conftest import read_png
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    img = pkg.Image(g.width, g.height)
+    devs = (ctypes.c_int * 1)(0)
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    job = pkg.host.rtu_begin_render(scene._h, img._h, devs, 1, rp.encode(), zp.encode())
+    assert job
+    assert pkg.host.rtu_render_wait(job) == 0, pkg.host.rtu_host_last_error()
+    pkg.host.rtu_render_job_free(job)
+    assert pkg.host.rtu_image_is_done(img._h)
+    zimg = read_png(zp)
+    assert np.array_equal(zimg, g.npz["zbuffer_u8"])
+    rgb = read_png(rp)
+    assert np.abs(rgb.astype(np.int32) - g.npz["result_u8"].astype(np.int32)).max() <= RGB8_TOL
+
+
+def test_errors_are_codes_not_crashes(pkg, ctx, golden):
+    g = golden("p1_256")
+    scene = g.scene(pkg)
+    fr = pkg.frame_setup(scene.desc.camera, 16, 16)
+    fresh = pkg.Context(0)
+    out = np.empty((16, 16, 4), np.float32)
+    assert pkg.hip.rtu_render_frame(fresh._h, ctypes.byref(fr), out.ctypes.data, None) == pkg.RTU_ERR_NO_SCENE
+    fresh.close()
+    bad = pkg.frame_setup(scene.desc.camera, 16, 16, shard_rank=2, shard_count=2)
+    ctx.upload(scene)
+    assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(bad), out.ctypes.data, None) == pkg.RTU_ERR_ARG
+    err = ctypes.c_int(0)
+    assert not pkg.hip.rtu_create_context(9999, ctypes.byref(err))
+    assert err.value == pkg.RTU_ERR_NO_DEVICE

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the render hot path on N MI355X (one process per GPU).
+
+A "step" is one frame of the headline workload: SceneFiles/Teapot/scene2.xml (cyTriMesh
+teapot behind a cyBVH, a refractive sphere, a ground plane, point + direct light) at
+1920x1080, recipe W (one ray per pixel centre, Shade depth 5) — the bit-exact teapot
+gate of BASELINE.md config 4. The scene is the flattened blob committed under
+tests/golden/ (the GPU box has no scene files); it is uploaded to HBM once, before the
+timed region.
+
+N=1: python bench.py.  N>1: launched by torch.distributed.run, one rank per GPU; the
+frame is sharded by interleaved 8-row bands (band b -> rank b % N, scene replicated,
+no data-path collective) and every step ends with the RCCL gather of the framebuffer
+(all_gather of the padded float4 shards over xGMI), which is inside the timed region.
+Scaling is "strong": the frame (total work) is fixed as N grows.
+
+Output: ONE JSON line on rank 0 (see the task contract) with `roofline` (algorithmic
+bytes of SURVEY.md §8(d) / HIP-event kernel time / 8 TB/s) and, at N=1, `cpu_baseline`
+(the CPU oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOAD_TAG = "teapot2_1080"
+WORKLOAD_NAME = "SceneFiles/Teapot/scene2.xml @1920x1080, recipe W (1 spp, Shade depth 5)"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tag", default=WORKLOAD_TAG, help="golden tag to render (default: the headline workload)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (CPU share of one GPU)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtu_sharding", os.path.join(REPO, "raytracer-utah_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    gdir = os.path.join(REPO, "tests", "golden", args.tag)
+    meta = json.load(open(os.path.join(gdir, "meta.json")))
+    W, H = meta["width"], meta["height"]
+    scene = pkg.Scene.from_blob_file(os.path.join(gdir, "scene.rtus.gz"))
+    ctx = pkg.Context(local_rank)
+    ctx.upload(scene)  # inputs resident in HBM before any timing
+
+    frame = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, max_bounce=args.max_bounce)
+    rows = pkg.shard_rows(frame)
+    max_rows = pkg.hip.rtu_shard_max_rows(H, world)
+    shard = torch.zeros(max_rows * W * 4, dtype=torch.float32, device=dev)
+    gathered = torch.empty(world * max_rows * W * 4, dtype=torch.float32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # -- untimed: ray / traversal counters of this shard (stats kernel variant) --------
+    sframe = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, collect_stats=True,
+                             max_bounce=args.max_bounce)
+    ctx.render_device(sframe, shard.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    keys = sorted(st)
+    tot = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=dev)
+    if dist:
+        dist.all_reduce(tot)
+    total = dict(zip(keys, [int(v) for v in tot.tolist()]))
+    rays_per_frame = pkg.total_rays(total)
+    alg_bytes_launch = pkg.algorithmic_bytes(st, rows * W)  # this rank's launch
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        ctx.render_device(frame, shard.data_ptr(), stream)
+        if ev:
+            ev[1].record()
+        if dist:
+            sharding.gather_framebuffer(shard, gathered, dist)  # RCCL over xGMI
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # HIP events on the launch stream
+
+    t = torch.tensor([elapsed, kernel_ms, float(alg_bytes_launch)], dtype=torch.float64, device=dev)
+    if dist:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        # roofline of the dominant kernel: the slowest rank's launch
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        slow = max(allt, key=lambda x: float(x[1]))
+        kernel_ms, alg_bytes_launch = float(slow[1]), float(slow[2])
+
+    # -- untimed: parity of what was just rendered (z bit-exact vs the reference golden) ---
+    if dist:
+        img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).cpu().numpy(), scene.desc.camera, W, H, world)
+    else:
+        img = shard.view(max_rows, W, 4)[:H].cpu().numpy()
+    import hashlib
+    z_ok = hashlib.sha256(np.ascontiguousarray(img[..., 3]).tobytes()).hexdigest() == meta["sha256_z_f32"]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if world == 1 and args.tag == WORKLOAD_TAG and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("bytes_per_launch")
+        out = {
+            "metric": "Mrays/sec at 1920x1080 (primary + secondary + shadow rays per frame / frame time)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD_NAME if args.tag == WORKLOAD_TAG else args.tag, "width": W, "height": H,
+                       "rays_per_frame": rays_per_frame, "primary": total["primary_rays"],
+                       "secondary": total["secondary_rays"], "shadow": total["shadow_rays"],
+                       "sharding": "interleaved 8-row bands, RCCL all_gather of float4 framebuffer" if world > 1 else "single GPU",
+                       "z_bit_exact_vs_reference_golden": bool(z_ok)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes_launch)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(g, scene, W, H, rays_per_frame, args.cpu_seconds, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, max_threads):
+    """The CPU oracle (a port: bit-identical restatement of the reference's Trace/Shade,
+    see oracle/rtu_oracle.cpp) on this box's host cores, same workload, whole frames
+    repeated until ~budget_s of wall time has been spent."""
+    orc = g.load_oracle()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, max_threads))
+    t0 = time.perf_counter()
+    orc.render(scene, W, H, threads=1)
+    t1 = time.perf_counter() - t0
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        orc.render(scene, W, H, threads=cores)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > max(1.0, budget_s - t1) or frames >= 200:
+            break
+    return {"value": round(rays_per_frame * frames / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d full 1920x1080 frames of the same workload on %d threads (row-chunk schedule); "
+                      "1 thread: %.3f Mrays/s" % (frames, cores, rays_per_frame / t1 / 1e6),
+            "ms_per_frame": round(el / frames * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    main()

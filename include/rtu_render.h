@@ -96,7 +96,7 @@ int  rtu_shard_global_row(const RtuFrameDesc* frame, int local_row);
 
 /* Render this context's shard into DEVICE memory d_rgbz (rtu_shard_rows * width
  * float4, 16-byte aligned), asynchronously on hip_stream (a hipStream_t passed
- * as void*; NULL = the context's own stream). Inputs are already resident in
+ * as void*; NULL = the device's default stream, as in HIP itself). Inputs are already resident in
  * HBM; nothing is copied. */
 int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream);
 

@@ -291,18 +291,21 @@ __device__ __forceinline__ bool mesh_hit(const DevMesh& mesh, const Ray& ray, Hi
 // later intersection tests, so applying FromNodeCoords for the hit node and all of
 // its ancestors immediately is equivalent to the reference applying them as the
 // recursion unwinds.
-template <bool SHADOW, int STACK, bool STATS>
-__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, Hit& h, uint32_t* stk, Counters& cnt) {
+//
+// ONE instantiation serves both kinds of ray: `shadow` is a per-lane flag, so
+// lanes casting shadow rays and lanes casting reflection / refraction rays walk
+// the scene together (better SIMD occupancy, a quarter of the code size of four
+// specialised copies — the kernel has to stay inside the instruction cache).
+template <int STACK, bool STATS>
+__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
     bool any = false;
     Ray r0 = to_node(s.nodes[0], wr);  // ray inside the root node
     Ray rp = r0;                       // ray inside node `rp_node` (cached parent space)
     int rp_node = 0;
-    bool done = false;
     for (uint32_t k = 0; k < s.n_nodes; k++) {
         const DevNode& n = s.nodes[k];
         if (n.obj_type == RTU_OBJ_NONE) continue;
-        if (done) continue;
-        // ray in the parent's inner space
+        if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
         int parent = n.parent;
         Ray pr;
         if (parent < 0) {
@@ -325,9 +328,7 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, Hit& h, 
         else hit = mesh_hit<STACK, STATS>(s.meshes[n.mesh_id], lr, h, stk, cnt);
         if (hit) {
             any = true;
-            if (SHADOW) {
-                done = true;  // first occluder wins (:223-225); stay in the loop for wave-uniform control flow
-            } else {
+            if (!shadow) {
                 h.node = (int)k;
                 from_node(n, h);
                 for (int j = parent; j >= 0; j = s.nodes[j].parent) from_node(s.nodes[j], h);
@@ -335,60 +336,6 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, Hit& h, 
         }
     }
     return any;
-}
-
-// GenLight::Shadow (lightFunctions.cpp:27-37)
-template <int STACK, bool STATS>
-__device__ __forceinline__ float shadow(const DevScene& s, const Ray& ray, float t_max, uint32_t* stk, Counters& cnt) {
-    RTU_CNT(shd);
-    Hit h;
-    h.z = t_max;
-    h.front = true;
-    h.node = -1;
-    h.p = mk3(0, 0, 0);
-    h.N = mk3(0, 0, 0);
-    if (trace<true, STACK, STATS>(s, ray, h, stk, cnt)) {
-        if (h.z > 0.0f) return 0.0f;
-    }
-    return 1.0f;
-}
-
-// Direct lighting of MtlBlinn::Shade (mtlFunctions.cpp:125-155) with
-// Ambient/Direct/PointLight::Illuminate (lights.h:32,48; lightFunctions.cpp:39-84).
-template <int STACK, bool STATS>
-__device__ __forceinline__ f3 direct_light(const DevScene& s, const RtuMaterial& m, f3 cam_pos, f3 p, f3 N, bool front,
-                                           uint32_t* stk, Counters& cnt) {
-    f3 result = mk3(0, 0, 0);
-    if (!front) return result;
-    f3 diffuse = ld3(m.diffuse), specular = ld3(m.specular);
-    for (uint32_t i = 0; i < s.n_lights; i++) {
-        const RtuLight& l = s.lights[i];
-        f3 intensity = ld3(l.intensity);
-        if (l.type == RTU_LIGHT_AMBIENT) {
-            result = result + diffuse * intensity;  // :132
-        } else {
-            f3 viewDirection = norm3(cam_pos - p);  // :137
-            f3 lvec = ld3(l.vec);
-            f3 ldir = (l.type == RTU_LIGHT_DIRECT) ? lvec : norm3(p - lvec);  // Direction(), lights.h:49,83
-            f3 lightDirection = norm3(-ldir);                                   // :138
-            f3 halfVector = norm3(viewDirection + lightDirection);              // :139
-            float NDotL = dot3(N, lightDirection);
-            float NDotH = dot3(N, halfVector);
-            if (NDotL < 0.0f) NDotL = 0.0f;
-            if (NDotH < 0.0f) NDotH = 0.0f;
-            f3 illum;
-            if (l.type == RTU_LIGHT_DIRECT) {
-                Ray sr; sr.p = p; sr.dir = -lvec;
-                illum = intensity * shadow<STACK, STATS>(s, sr, RTU_BIGFLOAT, stk, cnt);  // lights.h:48
-            } else {
-                Ray sr; sr.p = p; sr.dir = norm3(lvec - p);                                // :76
-                float sh = 0.0f + shadow<STACK, STATS>(s, sr, len3(lvec - p), stk, cnt);  // :78
-                illum = (intensity * sh) * (1 / dot3(lvec - p, lvec - p));                // :83
-            }
-            result = result + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
-        }
-    }
-    return result;
 }
 
 // sampledNormal of mtlFunctions.cpp:162-165 / :275-277 with SampleSphere(...,0) == (0,0,0)
@@ -440,9 +387,11 @@ __device__ __forceinline__ f3 absorb(float z, f3 absorption) {  // :213-215, :25
     return mk3(expf((-z) * absorption.x), expf((-z) * absorption.y), expf((-z) * absorption.z));
 }
 
-// Stage of a Shade() frame = where to resume after a child call returns.
+// Stage of a Shade() frame = where the lane resumes.
 enum Stage {
-    ST_REFR_START = 0,  // :160
+    ST_PRIMARY = 0,     // fire the primary ray
+    ST_LIGHT,           // direct lighting loop over lights, mtlFunctions.cpp:125-155
+    ST_REFR_START,      // :160
     ST_TIR_RET,         // child = TIR-reflected hit, :217-221
     ST_REFR_B_RET,      // child = refracted hit ("refractionResult"), :254
     ST_REFR_A_RET,      // child = Fresnel-reflected hit ("frenselResult"), :247
@@ -450,6 +399,8 @@ enum Stage {
     ST_REFL_RET,        // child = mirror-reflected hit, :286
     ST_DONE
 };
+// What the ray in flight is for (decides how its result is consumed).
+enum Pending { P_NONE = 0, P_PRIMARY, P_SHADOW, P_TIR, P_REFR_B, P_REFR_A, P_REFL };
 
 struct Frame {
     f3    dir, p, N;       // incoming ray direction, hit point, hit normal (world)
@@ -500,150 +451,226 @@ __global__ void __launch_bounds__(64) render_kernel(KernelArgs a) {
     const uint32_t band_local = tile / a.tiles_x;
     const uint32_t tx = tile - band_local * a.tiles_x;
     const int x = (int)(tx * 8 + (lane & 7));
-    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                       // row inside the shard
+    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
     const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
     uint32_t* stk = s_stack + lane;
     const uint32_t tid = blockIdx.x * 64 + lane;
     Counters cnt = {};
     const bool valid = x < a.frame.width && y < a.frame.height;
+    const f3 cam_pos = ld3(a.frame.cam_pos);
+    const f3 env = ld3(s.environment);
 
-    if (valid) {
-        // primary ray: RenderFunctions.cpp:258-268 (pixel centre), :97
-        f3 cam_pos = ld3(a.frame.cam_pos);
-        f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
-        Ray ray;
-        ray.p = cam_pos;
-        ray.dir = norm3(cp - cam_pos);
-        Hit h;
-        h.z = RTU_BIGFLOAT; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
-        RTU_CNT(prim);
-        bool hit = trace<false, STACK, STATS>(s, ray, h, stk, cnt);
-        const float z = h.z;
-        f3 color;
-        if (!hit) {
-            color = ld3(s.background);  // :145
-        } else {
-            RTU_CNT(prim_hit);
-            int mid = s.nodes[h.node].material_id;
-            if (mid < 0) {
-                color = mk3(1, 1, 1);  // null material => white
-            } else {
-                Frame F;
-                F.dir = ray.dir; F.p = h.p; F.N = h.N; F.front = h.front;
-                F.mtl = mid; F.bounce = a.frame.max_bounce;
-                F.term1 = mk3(0, 0, 0); F.aux = 0; F.aux_front = true;
-                F.result = direct_light<STACK, STATS>(s, s.materials[mid], cam_pos, F.p, F.N, F.front, stk, cnt);
-                F.stage = ST_REFR_START;
-                int level = 0;
-                f3 ret = mk3(0, 0, 0);  // value returned by the child frame that just finished
-                for (;;) {
-                    const RtuMaterial& m = s.materials[F.mtl];
-                    f3 refraction = ld3(m.refraction), reflection = ld3(m.reflection), absorption = ld3(m.absorption);
-                    bool want = false;      // this iteration fires one secondary ray
-                    Ray nr;                 // the ray
-                    int hit_stage = ST_DONE;  // stage the parent resumes at when the ray hits
-                    nr.p = F.p; nr.dir = mk3(0, 0, 0);
-                    if (F.stage == ST_REFR_START) {
-                        if (F.bounce > 0 && not_black(refraction)) {
-                            Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                            if (r.sinTheta2 > 1) {  // total internal reflection, :205
-                                nr.dir = reflect_dir(F.dir, r.sn);
-                                hit_stage = ST_TIR_RET;
-                            } else {
-                                nr.dir = norm3((-r.sn) * r.cosTheta2 + r.SVector * r.sinTheta2);  // :229
-                                hit_stage = ST_REFR_B_RET;
-                            }
-                            want = true;
-                        } else {
-                            F.stage = (F.bounce > 0) ? ST_REFL_START : ST_DONE;
-                        }
-                    } else if (F.stage == ST_TIR_RET) {
-                        f3 absorptionV = absorb(RTU_BIGFLOAT, absorption);  // z of a fresh HitInfo, :210-215
-                        F.result = F.result + absorptionV * ret;            // :219-221
-                        F.stage = ST_REFL_START;
-                    } else if (F.stage == ST_REFR_B_RET) {
-                        Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                        float S = schlick(r);
-                        f3 absorptionV = mk3(1, 1, 1);
-                        if (!F.aux_front) absorptionV = absorb(F.aux, absorption);  // :258-262
-                        F.term1 = ((absorptionV * refraction) * ret) * (float)(1.0 - (double)S);
-                        nr.dir = reflect_dir(F.dir, r.sn);  // Fresnel reflection ray, :239
-                        hit_stage = ST_REFR_A_RET;
-                        want = true;
-                    } else if (F.stage == ST_REFR_A_RET) {
-                        Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                        float S = schlick(r);
-                        f3 frenselResult = refraction * ret;                 // :247
-                        F.result = F.result + (F.term1 + frenselResult * S);  // :264
-                        F.stage = ST_REFL_START;
-                    } else if (F.stage == ST_REFL_START) {
-                        if (not_black(reflection)) {  // :273 (bounce > 0 is implied by reaching this stage)
-                            f3 sn = sampled_normal(F.p, F.N);
-                            nr.dir = reflect_dir(F.dir, sn);  // :280
-                            hit_stage = ST_REFL_RET;
-                            want = true;
-                        } else {
-                            F.stage = ST_DONE;
-                        }
-                    } else if (F.stage == ST_REFL_RET) {
-                        F.result = F.result + reflection * ret;  // :286
-                        F.stage = ST_DONE;
-                    }
+    // ---- per-lane state of the explicit Shade() recursion -------------------------
+    Frame F;
+    F.dir = F.p = F.N = F.result = F.term1 = mk3(0, 0, 0);
+    F.aux = 0; F.mtl = 0; F.bounce = 0; F.front = true; F.aux_front = true;
+    F.stage = ST_PRIMARY;
+    int level = 0;
+    uint32_t li = 0;             // next light of the ST_LIGHT loop
+    f3 ret = mk3(0, 0, 0);       // value returned by the child frame that just finished
+    f3 color = mk3(0, 0, 0);     // final pixel colour
+    float zprim = RTU_BIGFLOAT;  // hInfo.z of the primary ray
+    f3 lightK = mk3(0, 0, 0);    // diffuse + specular*pow(N.H, gloss) of the light whose shadow ray is in flight
+    float lightNDotL = 0;
+    bool fin = !valid;
 
-                    if (want) {
-                        RTU_CNT(sec);
-                        Hit ch;
-                        ch.z = RTU_BIGFLOAT; ch.front = true; ch.node = -1; ch.p = mk3(0, 0, 0); ch.N = mk3(0, 0, 0);
-                        bool chit = trace<false, STACK, STATS>(s, nr, ch, stk, cnt);
-                        f3 env = ld3(s.environment);
-                        if (chit) {
-                            int cmid = s.nodes[ch.node].material_id;
-                            if (hit_stage == ST_REFR_B_RET) { F.aux = ch.z; F.aux_front = ch.front; }
-                            F.stage = hit_stage;
-                            if (cmid < 0) {
-                                ret = mk3(1, 1, 1);  // null material (the reference would crash here)
-                            } else {
-                                frame_store(a.arena, a.n_threads, tid, level, F);
-                                level++;
-                                Frame C;
-                                C.dir = nr.dir; C.p = ch.p; C.N = ch.N; C.front = ch.front;
-                                C.mtl = cmid; C.bounce = F.bounce - 1;
-                                C.term1 = mk3(0, 0, 0); C.aux = 0; C.aux_front = true;
-                                C.result = direct_light<STACK, STATS>(s, s.materials[cmid], cam_pos, C.p, C.N, C.front, stk, cnt);
-                                C.stage = ST_REFR_START;
-                                F = C;
-                            }
-                        } else {
-                            // miss handling of the three call sites
-                            if (hit_stage == ST_TIR_RET) {
-                                F.stage = ST_REFL_START;  // :217 (no else branch)
-                            } else if (hit_stage == ST_REFR_B_RET) {
-                                F.result = F.result + env;  // :267
-                                F.stage = ST_REFL_START;
-                            } else if (hit_stage == ST_REFR_A_RET) {
-                                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                                float S = schlick(r);
-                                F.result = F.result + (F.term1 + env * S);  // :250, :264
-                                F.stage = ST_REFL_START;
-                            } else {
-                                F.result = F.result + env * reflection;  // :289
-                                F.stage = ST_DONE;
-                            }
-                        }
-                    }
-
-                    if (F.stage == ST_DONE) {
-                        ret = F.result;
-                        if (level == 0) break;
-                        level--;
-                        frame_load(a.arena, a.n_threads, tid, level, F);
-                    }
+    while (!fin) {
+        // ======== phase A: run the lane's frame until it needs a ray (or finishes) ========
+        int pend = P_NONE;
+        Ray nr;
+        nr.p = F.p; nr.dir = mk3(0, 0, 0);
+        float tmax = RTU_BIGFLOAT;
+        while (pend == P_NONE && !fin) {
+            if (F.stage == ST_PRIMARY) {
+                // RenderFunctions.cpp:258-268 (pixel centre), :97
+                f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
+                nr.p = cam_pos;
+                nr.dir = norm3(cp - cam_pos);
+                RTU_CNT(prim);
+                pend = P_PRIMARY;
+            } else if (F.stage == ST_LIGHT) {
+                if (!F.front || li >= s.n_lights) {  // :125 only front faces are lit
+                    F.stage = ST_REFR_START;
+                    continue;
                 }
-                color = ret;
+                const RtuLight& l = s.lights[li];
+                const RtuMaterial& m = s.materials[F.mtl];
+                f3 intensity = ld3(l.intensity);
+                f3 diffuse = ld3(m.diffuse);
+                if (l.type == RTU_LIGHT_AMBIENT) {
+                    F.result = F.result + diffuse * intensity;  // :132
+                    li++;
+                    continue;
+                }
+                f3 viewDirection = norm3(cam_pos - F.p);  // :137
+                f3 lvec = ld3(l.vec);
+                bool isDirect = l.type == RTU_LIGHT_DIRECT;
+                f3 ldir = isDirect ? lvec : norm3(F.p - lvec);          // Direction(), lights.h:49,83
+                f3 lightDirection = norm3(-ldir);                      // :138
+                f3 halfVector = norm3(viewDirection + lightDirection);  // :139
+                float NDotL = dot3(F.N, lightDirection);
+                float NDotH = dot3(F.N, halfVector);
+                if (NDotL < 0.0f) NDotL = 0.0f;
+                if (NDotH < 0.0f) NDotH = 0.0f;
+                lightNDotL = NDotL;
+                lightK = diffuse + ld3(m.specular) * powf(NDotH, m.glossiness);  // :152
+                nr.p = F.p;
+                if (isDirect) {
+                    nr.dir = -lvec;  // lights.h:48
+                    tmax = RTU_BIGFLOAT;
+                } else {
+                    nr.dir = norm3(lvec - F.p);  // lightFunctions.cpp:76
+                    tmax = len3(lvec - F.p);     // :78
+                }
+                RTU_CNT(shd);
+                pend = P_SHADOW;
+            } else if (F.stage == ST_REFR_START) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                if (F.bounce > 0 && not_black(ld3(m.refraction))) {
+                    Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
+                    if (r.sinTheta2 > 1) {  // total internal reflection, :205
+                        nr.dir = reflect_dir(F.dir, r.sn);
+                        pend = P_TIR;
+                    } else {
+                        nr.dir = norm3((-r.sn) * r.cosTheta2 + r.SVector * r.sinTheta2);  // :229
+                        pend = P_REFR_B;
+                    }
+                    nr.p = F.p;
+                    RTU_CNT(sec);
+                } else {
+                    F.stage = (F.bounce > 0) ? ST_REFL_START : ST_DONE;
+                }
+            } else if (F.stage == ST_TIR_RET) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                f3 absorptionV = absorb(RTU_BIGFLOAT, ld3(m.absorption));  // z of a fresh HitInfo, :210-215
+                F.result = F.result + absorptionV * ret;                    // :219-221
+                F.stage = ST_REFL_START;
+            } else if (F.stage == ST_REFR_B_RET) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
+                float S = schlick(r);
+                f3 absorptionV = mk3(1, 1, 1);
+                if (!F.aux_front) absorptionV = absorb(F.aux, ld3(m.absorption));  // :258-262
+                F.term1 = ((absorptionV * ld3(m.refraction)) * ret) * (float)(1.0 - (double)S);
+                nr.p = F.p;
+                nr.dir = reflect_dir(F.dir, r.sn);  // Fresnel reflection ray, :239
+                RTU_CNT(sec);
+                pend = P_REFR_A;
+            } else if (F.stage == ST_REFR_A_RET) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
+                float S = schlick(r);
+                f3 frenselResult = ld3(m.refraction) * ret;           // :247
+                F.result = F.result + (F.term1 + frenselResult * S);  // :264
+                F.stage = ST_REFL_START;
+            } else if (F.stage == ST_REFL_START) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                if (not_black(ld3(m.reflection))) {  // :273 (bounce > 0 is implied by reaching this stage)
+                    f3 sn = sampled_normal(F.p, F.N);
+                    nr.p = F.p;
+                    nr.dir = reflect_dir(F.dir, sn);  // :280
+                    RTU_CNT(sec);
+                    pend = P_REFL;
+                } else {
+                    F.stage = ST_DONE;
+                }
+            } else if (F.stage == ST_REFL_RET) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                F.result = F.result + ld3(m.reflection) * ret;  // :286
+                F.stage = ST_DONE;
+            } else {  // ST_DONE: return to the caller frame
+                ret = F.result;
+                if (level == 0) {
+                    color = ret;
+                    fin = true;
+                } else {
+                    level--;
+                    frame_load(a.arena, a.n_threads, tid, level, F);
+                }
             }
         }
-        a.out[(size_t)ly * a.frame.width + x] = make_float4(color.x, color.y, color.z, z);
+        if (fin) break;
+
+        // ======== phase B: the one ray-scene intersection site of the kernel ========
+        Hit h;
+        h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
+        const bool is_shadow = pend == P_SHADOW;
+        const bool hit = trace<STACK, STATS>(s, nr, is_shadow, h, stk, cnt);
+
+        // ======== phase C: consume the result ========
+        if (is_shadow) {
+            // GenLight::Shadow (lightFunctions.cpp:27-37) + Illuminate (lights.h:48, lightFunctions.cpp:75-83)
+            float sh = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
+            const RtuLight& l = s.lights[li];
+            f3 intensity = ld3(l.intensity);
+            f3 illum;
+            if (l.type == RTU_LIGHT_DIRECT) {
+                illum = intensity * sh;
+            } else {
+                f3 d = ld3(l.vec) - F.p;
+                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // :83
+            }
+            F.result = F.result + (illum * lightNDotL) * lightK;  // mtlFunctions.cpp:152
+            li++;
+        } else if (pend == P_PRIMARY) {
+            zprim = h.z;
+            if (!hit) {
+                color = ld3(s.background);  // RenderFunctions.cpp:145
+                fin = true;
+            } else {
+                RTU_CNT(prim_hit);
+                int mid = s.nodes[h.node].material_id;
+                if (mid < 0) {
+                    color = mk3(1, 1, 1);  // null material => white
+                    fin = true;
+                } else {
+                    F.dir = nr.dir; F.p = h.p; F.N = h.N; F.front = h.front;
+                    F.mtl = mid; F.bounce = a.frame.max_bounce;
+                    F.result = mk3(0, 0, 0);
+                    F.stage = ST_LIGHT;
+                    li = 0;
+                }
+            }
+        } else if (hit) {
+            // a secondary ray hit: Shade() of the hit node becomes the active frame
+            int ret_stage = pend == P_TIR ? ST_TIR_RET : pend == P_REFR_B ? ST_REFR_B_RET : pend == P_REFR_A ? ST_REFR_A_RET : ST_REFL_RET;
+            if (pend == P_REFR_B) { F.aux = h.z; F.aux_front = h.front; }
+            F.stage = ret_stage;
+            int cmid = s.nodes[h.node].material_id;
+            if (cmid < 0) {
+                ret = mk3(1, 1, 1);  // null material (the reference would crash here)
+            } else {
+                frame_store(a.arena, a.n_threads, tid, level, F);
+                level++;
+                int cb = F.bounce - 1;
+                F.dir = nr.dir; F.p = h.p; F.N = h.N; F.front = h.front;
+                F.mtl = cmid; F.bounce = cb;
+                F.result = mk3(0, 0, 0); F.term1 = mk3(0, 0, 0); F.aux = 0; F.aux_front = true;
+                F.stage = ST_LIGHT;
+                li = 0;
+            }
+        } else {
+            // a secondary ray missed
+            if (pend == P_TIR) {
+                F.stage = ST_REFL_START;  // :217 has no else branch
+            } else if (pend == P_REFR_B) {
+                F.result = F.result + env;  // :267
+                F.stage = ST_REFL_START;
+            } else if (pend == P_REFR_A) {
+                const RtuMaterial& m = s.materials[F.mtl];
+                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
+                float S = schlick(r);
+                F.result = F.result + (F.term1 + env * S);  // :250, :264
+                F.stage = ST_REFL_START;
+            } else {
+                const RtuMaterial& m = s.materials[F.mtl];
+                F.result = F.result + env * ld3(m.reflection);  // :289
+                F.stage = ST_DONE;
+            }
+        }
     }
+
+    if (valid) a.out[(size_t)ly * a.frame.width + x] = make_float4(color.x, color.y, color.z, zprim);
 
     if (STATS) {
         // wave reduction, then one atomic per counter per wave

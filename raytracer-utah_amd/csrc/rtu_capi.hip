@@ -376,7 +376,7 @@ int rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_
     if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
     if (!d_rgbz && rtu_shard_rows(frame) > 0) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
     return launch(ctx, frame, (float4*)d_rgbz, st, true);
 }
 
@@ -422,7 +422,7 @@ int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, vo
     if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
     if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t st = (hipStream_t)hip_stream;
     RTU_HIP(ctx, hipEventRecord(ctx->ev0, st));
     for (int i = 0; i < iters; i++) {
         rc = launch(ctx, frame, (float4*)d_rgbz, st, i == 0);

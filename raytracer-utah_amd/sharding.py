@@ -1,0 +1,30 @@
+"""Multi-GPU plumbing: one process per GPU, the frame sharded by interleaved 8-row
+bands, one gather of the float4 framebuffer per frame over
+torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
+tests). No data-path collective besides that gather: the scene (<= 0.5 MB) is replicated."""
+import numpy as np
+
+
+def gather_framebuffer(shard, gathered, dist):
+    """All ranks contribute their padded shard [max_rows*W*4]; `gathered` is
+    [world*max_rows*W*4] on every rank."""
+    dist.all_gather_into_tensor(gathered, shard)
+    return gathered
+
+
+def assemble_gathered(pkg, gathered_np, camera, width, height, world):
+    """De-interleave a gathered [world, max_rows, W, 4] array into the [H, W, 4] frame."""
+    frames = [pkg.frame_setup(camera, width, height, shard_rank=r, shard_count=world) for r in range(world)]
+    return pkg.assemble([gathered_np[r] for r in range(world)], frames, height)
+
+
+def global_minmax_z(z_local, dist, torch):
+    """z-image normalisation needs the frame-wide zmin/zmax (scene.h:596-601): a 2-float
+    all-reduce when the frame is not gathered to one place."""
+    hit = z_local[z_local != 1.0e30]
+    lo = hit.min() if hit.numel() else torch.tensor(1.0e30, dtype=z_local.dtype, device=z_local.device)
+    hi = hit.max() if hit.numel() else torch.tensor(0.0, dtype=z_local.dtype, device=z_local.device)
+    lo, hi = lo.clone().reshape(1), hi.clone().reshape(1)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo), float(hi)

@@ -78,6 +78,7 @@ def main():
         np.savez_compressed(os.path.join(dst, "golden.npz"), **arrays)
         json.dump(meta, open(os.path.join(dst, "meta.json"), "w"), indent=1, sort_keys=True)
         print(tag, meta["primary_hits"], meta["secondary"], meta["shadow"])
+        shutil.rmtree(src)  # the raw dumps are large (40 MB per 1080p config); the fixtures are what is kept
 
 
 if __name__ == "__main__":

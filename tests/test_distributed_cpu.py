@@ -1,0 +1,68 @@
+"""world_size-2 (and 3) gloo test of the multi-GPU path on CPU: shard arithmetic,
+padded all_gather of the float4 framebuffer, de-interleave. The renderer of each rank
+is stood in for by the oracle (test infrastructure) rendering exactly the rows the
+rank's GPU would render, so the assembled frame must equal the single-process frame."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tag, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import __graft_entry__ as g
+    pkg, orc = g.load_package(), g.load_oracle()
+    spec = __import__("importlib.util").util.spec_from_file_location(
+        "rtu_sharding", os.path.join(repo, "raytracer-utah_amd", "sharding.py"))
+    sharding = __import__("importlib.util").util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    gdir = os.path.join(repo, "tests", "golden", tag)
+    scene = pkg.Scene.from_blob_file(os.path.join(gdir, "scene.rtus.gz"))
+    W, H = scene.desc.camera.img_width, scene.desc.camera.img_height
+    frame = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world)
+    rows = pkg.shard_global_rows(frame)
+    max_rows = pkg.hip.rtu_shard_max_rows(H, world)
+    shard = torch.zeros(max_rows * W * 4, dtype=torch.float32)
+    buf = shard.view(max_rows, W, 4).numpy()
+    for lr in range(0, len(rows), 8):  # band by band, as the kernel's grid does
+        n = min(8, len(rows) - lr)
+        part, _ = orc.render(scene, W, H, threads=1, row0=int(rows[lr]), nrows=n)
+        buf[lr:lr + n] = part
+    gathered = torch.empty(world * max_rows * W * 4, dtype=torch.float32)
+    sharding.gather_framebuffer(shard, gathered, dist)
+    lo, hi = sharding.global_minmax_z(shard.view(max_rows, W, 4)[:len(rows), :, 3], dist, torch)
+    img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).numpy(), scene.desc.camera, W, H, world)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
+    np.save(os.path.join(out_dir, "minmax%d.npy" % rank), np.float32([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_reassembles_the_frame(pkg, orc, golden, tmp_path, world):
+    import torch.multiprocessing as mp
+    tag = "teapot2_240x135"
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, tag, str(tmp_path)), nprocs=world, join=True)
+    g = golden(tag)
+    ref, _ = orc.render(g.scene(pkg), g.width, g.height, threads=2)
+    z = ref[..., 3]
+    for r in range(world):
+        img = np.load(tmp_path / ("rank%d.npy" % r))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "rank %d assembled a different frame" % r
+        lo, hi = np.load(tmp_path / ("minmax%d.npy" % r))
+        assert lo == z[z != np.float32(1e30)].min() and hi == z[z != np.float32(1e30)].max()

@@ -1,0 +1,211 @@
+"""CPU-only tests of the host side of the boundary and of the C-ABI's shape:
+the libraries load and export every symbol include/*.h declares (no compute calls
+without a GPU), the loader reproduces the reference's scene values bit for bit, the
+RenderImage mirror post-processes like the reference, shard arithmetic is consistent."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ALL_TAGS, REFERENCE, REPO, SMALL_TAGS, read_png
+
+MAC_PREFIX = "/Users/Peter/GitRepos/RayTracer-Utah"
+SCENES = {
+    "p1_256": "Project1Example.xml", "p3s_800x600": "Project3Simple.xml", "p4_1080": "Project4.xml",
+    "teapot2_1080": "Teapot/scene2.xml", "p11_1080": "Project11/scene.xml", "p4_240x135": "Project4.xml",
+    "teapot2_240x135": "Teapot/scene2.xml", "p11_240x135": "Project11/scene.xml",
+}
+
+
+def declared_symbols(header):
+    text = open(os.path.join(REPO, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol(pkg):
+    hip_syms = declared_symbols("rtu_render.h")
+    host_syms = declared_symbols("rtu_host.h")
+    assert len(hip_syms) >= 15 and len(host_syms) >= 25
+    for s in hip_syms:
+        assert hasattr(pkg.hip, s), "librtu_hip.so does not export " + s
+    for s in host_syms:
+        assert hasattr(pkg.host, s), "librtu_host.so does not export " + s
+    assert set(hip_syms) == set(pkg.HIP_SYMBOLS)
+    assert set(host_syms) == set(pkg.HOST_SYMBOLS)
+
+
+def test_struct_layouts_match_the_headers(pkg):
+    assert ctypes.sizeof(pkg.RtuFrameDesc) == 80
+    assert ctypes.sizeof(pkg.RtuStats) == 88
+    assert ctypes.sizeof(pkg.RtuCamera) == 56
+    assert ctypes.sizeof(pkg.RtuEnvColor) == 32
+
+
+def test_no_gpu_means_error_code_not_crash(pkg):
+    if pkg.hip.rtu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    err = ctypes.c_int(0)
+    assert not pkg.hip.rtu_create_context(0, ctypes.byref(err))
+    assert err.value == pkg.RTU_ERR_NO_DEVICE
+    assert b"GPU" in pkg.hip.rtu_error_string(err.value)
+
+
+@pytest.mark.parametrize("tag", ALL_TAGS)
+def test_blob_round_trip(pkg, golden, tag):
+    g = golden(tag)
+    s = g.scene(pkg)
+    blob = s.to_blob_bytes()
+    s2 = pkg.Scene.from_blob_bytes(blob)
+    assert s2.to_blob_bytes() == blob
+    d = s.desc
+    assert (d.camera.img_width, d.camera.img_height) == (g.width, g.height)
+    assert d.n_nodes >= 2
+
+
+def test_blob_rejects_garbage(pkg, golden):
+    blob = golden("p1_256").scene(pkg).to_blob_bytes()
+    for bad in (b"", b"nonsense" * 10, blob[:100], blob[:-64], b"X" + blob[1:]):
+        with pytest.raises(pkg.RtuError):
+            pkg.Scene.from_blob_bytes(bad)
+    # a count larger than the blob can hold must not allocate / crash
+    huge = bytearray(blob)
+    huge[8:12] = (0x7FFFFFFF).to_bytes(4, "little")
+    with pytest.raises(pkg.RtuError):
+        pkg.Scene.from_blob_bytes(bytes(huge))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="scene files only exist in the authoring container")
+@pytest.mark.parametrize("tag", ALL_TAGS)
+def test_loader_matches_reference_scene_values(pkg, golden, tag):
+    """Own XML + OBJ reader + BVH build vs the blob dumped from the reference's in-memory
+    scene graph after ITS LoadScene(): every float of every node/material/light/camera,
+    every mesh array and every BVH node identical."""
+    g = golden(tag)
+    s = pkg.Scene.from_xml(os.path.join(REFERENCE, "SceneFiles", SCENES[tag]), MAC_PREFIX, REFERENCE)
+    s.set_resolution(g.width, g.height)
+    assert s.to_blob_bytes() == g.scene(pkg).to_blob_bytes()
+
+
+def test_loader_error_paths(pkg, tmp_path):
+    with pytest.raises(pkg.RtuError, match="Failed to load"):
+        pkg.Scene.from_xml(str(tmp_path / "missing.xml"))
+    for text, msg in [("<xml><scene/></xml>", "camera"), ("<xml><camera/></xml>", "scene"), ("<foo/>", "xml"),
+                      ("<xml><scene><object></scene></xml>", "parse error")]:
+        p = tmp_path / "s.xml"
+        p.write_text(text)
+        with pytest.raises(pkg.RtuError, match=msg):
+            pkg.Scene.from_xml(str(p))
+
+
+def test_loader_defaults_and_transform_order(pkg, tmp_path):
+    """Attribute defaults of SURVEY Appendix E on a hand-written scene."""
+    p = tmp_path / "s.xml"
+    p.write_text("""<xml><scene>
+      <!-- comment -->
+      <object type="sphere" name="a" material="m"><scale value="2"/><translate x="1"/>
+        <object type="plane" name="b"><rotate angle="90" z="1"/></object></object>
+      <object name="missing-obj" type="obj"/>
+      <material type="blinn" name="m"><specular value="0"/><refraction value="0.5" index="1.5"/></material>
+      <material type="phong" name="ignored"/>
+      <light type="direct" name="d"><intensity value="2"/></light>
+      <light type="point" name="p"><position x="1" y="2" z="3"/></light>
+      <background r="0.25"/>
+    </scene><camera><position z="10"/><target/><fov value="50"/></camera></xml>""")
+    s = pkg.Scene.from_xml(str(p))
+    d = s.desc
+    assert d.n_nodes == 4 and d.n_materials == 1 and d.n_lights == 2
+    nodes = np.ctypeslib.as_array(ctypes.cast(d.nodes, ctypes.POINTER(ctypes.c_float)), (d.n_nodes, 32))
+    inodes = nodes.view(np.int32)
+    # node 1: scale 2 then translate (1,0,0): tm = 2I, pos = (1,0,0), itm = 0.5 I
+    assert np.array_equal(nodes[1, :9], np.diag([2, 2, 2]).astype(np.float32).ravel())
+    assert np.array_equal(nodes[1, 9:18], np.diag([.5, .5, .5]).astype(np.float32).ravel())
+    assert np.array_equal(nodes[1, 18:21], np.float32([1, 0, 0]))
+    assert list(inodes[:, 21]) == [-1, 0, 1, 0]          # parents (pre-order)
+    assert list(inodes[:, 22]) == [0, 1, 2, 0]           # types: group, sphere, plane, failed obj -> none
+    assert list(inodes[:, 24]) == [-1, 0, -1, -1]        # material ids
+    assert list(inodes[:, 26]) == [4, 3, 3, 4]           # subtree_end
+    mats = np.ctypeslib.as_array(ctypes.cast(d.materials, ctypes.POINTER(ctypes.c_float)), (1, 24))
+    assert np.array_equal(mats[0, :3], np.float32([.5, .5, .5]))     # diffuse default (materials.h:22)
+    assert np.array_equal(mats[0, 3:6], np.float32([0, 0, 0]))       # specular value=0 -> (1,1,1)*0
+    assert np.array_equal(mats[0, 9:12], np.float32([.5, .5, .5]))   # refraction value=0.5
+    assert mats[0, 18] == 20 and mats[0, 19] == 1.5                  # glossiness default, ior
+    lights = np.ctypeslib.as_array(ctypes.cast(d.lights, ctypes.POINTER(ctypes.c_float)), (2, 8))
+    assert np.array_equal(lights[0, 1:4], np.float32([2, 2, 2]))
+    assert np.array_equal(lights[0, 4:7], np.float32([0, 0, 1]))     # DirectLight default direction
+    assert np.array_equal(lights[1, 4:7], np.float32([1, 2, 3]))
+    assert list(d.background.color) == [0.25, 1.0, 1.0] and d.background.has_map == 0
+    assert list(d.environment.color) == [0.0, 0.0, 0.0]
+    cam = d.camera
+    assert list(cam.pos) == [0, 0, 10] and list(cam.dir) == [0, 0, -1] and list(cam.up) == [0, 1, 0]
+    assert (cam.fov, cam.img_width, cam.img_height) == (50, 200, 150)
+
+
+@pytest.mark.parametrize("tag", SMALL_TAGS + ["teapot2_1080"])
+def test_frame_setup_matches_oracle_camera_frame(pkg, orc, golden, tag):
+    """Row a3: CalculateImageOrigin / CalculateCurrentPoint hoisted to the host."""
+    g = golden(tag)
+    cam = g.scene(pkg).desc.camera
+    for (W, H) in [(g.width, g.height), (1920, 1080), (61, 45)]:
+        f = pkg.frame_setup(cam, W, H)
+        mine = np.float32([list(f.cam_pos), list(f.origin), list(f.u), list(f.v)])
+        ref = orc.camera_frame(cam, W, H)
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def test_shard_arithmetic(pkg, golden):
+    cam = golden("p1_256").scene(pkg).desc.camera
+    for H in (1, 7, 8, 9, 135, 1080, 1081):
+        for G in (1, 2, 3, 4, 8, 200):
+            seen = []
+            for r in range(G):
+                f = pkg.frame_setup(cam, 16, H, shard_rank=r, shard_count=G)
+                rows = pkg.shard_global_rows(f)
+                assert len(rows) == pkg.shard_rows(f) <= pkg.hip.rtu_shard_max_rows(H, G)
+                assert all((row // 8) % G == r for row in rows)
+                seen.extend(rows.tolist())
+            assert sorted(seen) == list(range(H)), (H, G)
+
+
+@pytest.mark.parametrize("tag", SMALL_TAGS)
+def test_render_image_mirror_matches_reference(pkg, orc, golden, tag, tmp_path):
+    """rtu_image_* (gamma, Color24, z-image, PNG) on the oracle's float output must give
+    the reference's Result / ZBuffer pixels exactly; bands may arrive in any order."""
+    g = golden(tag)
+    out, _ = orc.render(g.scene(pkg), g.width, g.height, threads=4)
+    img = pkg.Image(g.width, g.height)
+    order = list(range(0, g.height, 8))
+    for r0 in order[::-1]:
+        img.fill(out[r0:r0 + 8], r0)
+    assert pkg.host.rtu_image_is_done(img._h)
+    assert pkg.host.rtu_image_num_rendered(img._h) == g.width * g.height
+    img.compute_zimage()
+    assert np.array_equal(img.pixels(), g.npz["result_u8"])
+    assert np.array_equal(img.zimage(), g.npz["zbuffer_u8"])
+    assert np.array_equal(img.zbuffer().view(np.uint32), out[..., 3].view(np.uint32))
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    img.save(rp, zp)
+    assert np.array_equal(read_png(rp), g.npz["result_u8"])
+    assert np.array_equal(read_png(zp), g.npz["zbuffer_u8"])
+
+
+def test_color24_edge_cases(pkg):
+    """int(r*255) clamped; NaN / negative / huge behave as the reference's x86 build."""
+    img = pkg.Image(8, 1)
+    vals = np.float32([0.0, 1.0, 0.5, -1.0, 1e9, np.nan, 4.0, 1e-9])
+    px = np.zeros((1, 8, 4), np.float32)
+    px[0, :, 0] = vals
+    px[0, :, 3] = [1, 2, 1e30, 4, 5, 6, 7, 8]
+    img.fill(px, 0)
+    exp = []
+    for v in vals:
+        gam = np.float32(np.float64(v) ** (1 / 2.2)) if v >= 0 else np.float32(np.nan)
+        x = gam * np.float32(255)
+        i = -2**31 if not (np.isfinite(x) and -2.0**31 <= x < 2.0**31) else int(x)
+        exp.append(min(max(i, 0), 255))
+    assert list(img.pixels()[0, :, 0]) == exp
+    img.compute_zimage()
+    zi = img.zimage()[0]
+    assert zi[2] == 0 and zi[7] == 0 and zi[0] == 255  # miss -> 0, farthest -> 0, nearest -> 255

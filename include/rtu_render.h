@@ -42,6 +42,7 @@ extern "C" {
 #define RTU_ERR_STOCHASTIC  (-4)  /* soft shadows / glossy bounces / depth of field */
 #define RTU_ERR_NO_SCENE    (-5)  /* render before rtu_upload_scene */
 #define RTU_ERR_NO_DEVICE   (-6)  /* no such GPU */
+#define RTU_ERR_CAPACITY    (-7)  /* more Shade() frames than provisioned (see rtu_frame_status) */
 
 #define RTU_BAND_ROWS 8  /* image rows per band; one wavefront renders an 8x8 pixel tile */
 
@@ -103,6 +104,12 @@ int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d
 /* Render into the context's own framebuffer and copy the shard to host memory
  * h_rgbz (rtu_shard_rows * width * 4 floats). Synchronous. stats may be NULL. */
 int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, RtuStats* stats);
+
+/* After rtu_render_frame_device: wait for the device and report whether the frame is
+ * complete. The Shade() recursion is evaluated level by level in pre-sized frame
+ * arrays; RTU_ERR_CAPACITY means a level overflowed (the arrays are doubled, render the
+ * frame again). rtu_render_frame does this check and the re-render itself. */
+int  rtu_frame_status(RtuContext* ctx);
 
 /* Counters of the last frame rendered with collect_stats=1 (synchronises). */
 int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);

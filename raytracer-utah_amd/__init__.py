@@ -31,6 +31,7 @@ RTU_ERR_UNSUPPORTED = -3
 RTU_ERR_STOCHASTIC = -4
 RTU_ERR_NO_SCENE = -5
 RTU_ERR_NO_DEVICE = -6
+RTU_ERR_CAPACITY = -7
 
 
 class RtuError(RuntimeError):
@@ -112,7 +113,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_get_stats", "rtu_time_render", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_get_stats", "rtu_time_render", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -126,6 +127,7 @@ _sig(hip, "rtu_shard_max_rows", _I, _I, _I)
 _sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
 _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
+_sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_get_stats", _I, _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_time_render", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P, _I, ctypes.POINTER(ctypes.c_float))
 _sig(hip, "rtu_device_alloc", _P, _P, ctypes.c_size_t)
@@ -269,6 +271,10 @@ class Context:
 
     def render_device(self, frame, d_ptr, stream=None):
         self._check(hip.rtu_render_frame_device(self._h, ctypes.byref(frame), d_ptr, stream))
+
+    def frame_status(self):
+        """Synchronise; raises RtuError(RTU_ERR_CAPACITY) if the frame must be rendered again."""
+        self._check(hip.rtu_frame_status(self._h))
 
     def time_render(self, frame, d_ptr, stream, iters):
         ms = ctypes.c_float(0)

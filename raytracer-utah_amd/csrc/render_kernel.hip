@@ -1,449 +1,110 @@
-// render_kernel.hip — the per-pixel render hot path as one hand-written gfx950 kernel.
+// render_kernel.hip — the per-pixel render hot path as a LEVEL-SYNCHRONOUS WAVEFRONT
+// of hand-written gfx950 kernels. No MFMA: there is no dense contraction here.
 //
-// One 64-lane wavefront per workgroup renders one 8x8 pixel tile; each lane owns
-// a pixel for the whole recursion (primary ray -> closest hit through the scene
-// node tree and the mesh BVH -> Blinn shading with shadow rays -> reflection /
-// refraction bounces). No MFMA: there is no dense contraction on this path.
+// Why not one thread = one pixel for the whole recursion (round-1 v1 of this file):
+// rocprof showed the GPU ~95 % idle — a pixel on the glass sphere fires ~20 rays
+// ONE AFTER ANOTHER (depth-first Shade recursion), a wave is as slow as its slowest
+// lane, and a handful of such waves lasted as long as the whole launch
+// (profiles/r01_v1_*). The reference's recursion tree is therefore evaluated level
+// by level; everything that is independent runs in parallel across the chip:
+//
+//   k_primary      one 8x8 pixel tile per wavefront: primary ray -> closest hit; a miss
+//                  writes the pixel, a hit appends a level-0 "frame" (= one Shade() call)
+//   per level L = 0 .. max_bounce:
+//     k_trace(L)   one lane per (frame, ray slot): the shadow ray of every non-ambient
+//                  light, the refracted/TIR ray, the Fresnel ray, the mirror ray — slot-major,
+//                  so a wavefront traces 64 rays of the same kind for 64 neighbouring frames
+//     k_consume(L) one lane per frame: direct lighting in the reference's light order; hits
+//                  of secondary rays become frames of level L+1; a frame without children is final
+//   per level L = max_bounce-1 .. 0:
+//     k_combine(L) frames that wait for children combine them in the reference's exact term
+//                  order (mtlFunctions.cpp:205-291); level 0 writes the pixel
 //
 // What replaces what (reference file:line):
-//   tile/lane -> (x,y)            PixelIterator::GetPixelLocation   PixelIterator.h:25-38
-//   primary ray                   CalculateCurrentPoint + Ray        RenderFunctions.cpp:96-97,258-268
-//   trace<false>/trace<true>      Trace / ShadowTrace                RenderFunctions.cpp:181-240
-//   to_node / from_node           Node::ToNodeCoords/FromNodeCoords  scene.h:501-512
-//   box_slabs                     Box::IntersectRay, BVHBoxIntersection  objFunctions.cpp:143-254,408-522
-//   sphere_hit / plane_hit        Sphere/Plane::IntersectRay         objFunctions.cpp:15-140
-//   mesh_hit / tri_hit            TriObj::IntersectRay/IntersectTriangle  objFunctions.cpp:257-406
-//   direct_light / illuminate     MtlBlinn::Shade :125-155, Illuminate/Shadow  lightFunctions.cpp:27-84
-//   the stage machine in render   MtlBlinn::Shade :158-292 (recursion made explicit)
+//   tile/lane -> (x,y)     PixelIterator::GetPixelLocation          PixelIterator.h:25-38
+//   k_primary              Render(): ray set-up + Trace             RenderFunctions.cpp:96-103,258-268
+//   k_trace shadow slots   Light::Illuminate -> GenLight::Shadow    lightFunctions.cpp:27-84, lights.h:48
+//   k_trace secondary      MtlBlinn::Shade ray generation           mtlFunctions.cpp:160-229,239,273-283
+//   k_consume direct term  MtlBlinn::Shade light loop               mtlFunctions.cpp:125-155
+//   finalize()             MtlBlinn::Shade combination              mtlFunctions.cpp:205-291
+// The ray/scene arithmetic itself is in rtu_intersect.h.
 //
-// Bit parity: compiled -ffp-contract=off with IEEE divide/sqrt; every expression
-// keeps the reference's order and its float->double promotions.
-//
-// Recursion: Shade() calls itself up to depth 5 with a branching factor of up to
-// 3 and combines child results non-linearly, so the recursion is emulated
-// exactly with an explicit frame stack (17 floats per level) instead of a
-// throughput-weighted ray queue: the parent's partial sum, the pending term and
-// the hit are saved, the child frame runs, and the parent resumes at the stage it
-// left. Saved frames live in an HBM arena (one coalesced column per lane); the
-// BVH traversal stack, which is touched on every node visit, lives in LDS.
-#include "rtu_device.h"
+// Exactness: a frame's arithmetic is the same sequence of float operations as the
+// recursive code; only the ORDER IN WHICH INDEPENDENT FRAMES ARE EVALUATED changes.
+// In the fast variant the Fresnel ray is traced speculatively alongside the
+// refracted ray (its result is used only if the refracted ray hit, :234-251); the
+// counting variant (collect_stats) traces it in a second pass so that its ray and
+// traversal counters equal the CPU oracle's.
+#include "rtu_intersect.h"
 
 namespace {
 
-struct Ray {
-    f3 p, dir;
-};
+enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
+// k_trace slot selection bits
+enum { SEL_SHADOW = 1, SEL_MAIN = 2, SEL_A = 4, SEL_C = 8, SEL_A_NEEDS_B = 16 };
 
-struct Hit {  // HitInfo without uvw/duvw (no textures on this path) — scene.h:150-163
-    float z;
-    f3    p, N;
-    int   node;
-    bool  front;
-};
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-struct Counters {
-    unsigned prim, prim_hit, sec, shd, node, mesh, inner, leafv, leafe, tri, acc;
-};
-
-#define RTU_CNT(field) do { if (STATS) cnt.field++; } while (0)
-
-// ---------------------------------------------------------------------------
-// Node::ToNodeCoords (scene.h:501-507): p' = itm*(p-pos); d' = itm*((p+d)-pos) - p'
-__device__ __forceinline__ Ray to_node(const DevNode& n, const Ray& r) {
-    f3 pos = ld3(n.pos);
-    Ray o;
-    o.p = mat_mul(n.itm, r.p - pos);
-    o.dir = mat_mul(n.itm, (r.p + r.dir) - pos) - o.p;
-    return o;
-}
-// Node::FromNodeCoords (scene.h:508-512)
-__device__ __forceinline__ void from_node(const DevNode& n, Hit& h) {
-    h.p = mat_mul(n.tm, h.p) + ld3(n.pos);
-    h.N = norm3(mat_tmul(n.itm, h.N));
-}
-
-// ---------------------------------------------------------------------------
-// Slab interval of Box::IntersectRay / BVHBoxIntersection (objFunctions.cpp:143-254,
-// 408-522). The reference has four branches keyed on the first exactly-zero
-// direction component; each branch evaluates the same per-axis quotients and
-// only differs in which axes enter max/min, so the quotients are computed
-// unconditionally (IEEE: a division by zero cannot trap) and selected.
-__device__ __forceinline__ void box_slabs(const Ray& r, f3 bmin, f3 bmax, float& tEntry, float& tExit) {
-    float tx0 = (bmin.x - r.p.x) / r.dir.x;
-    float tx1 = (bmax.x - r.p.x) / r.dir.x;
-    float ty0 = (bmin.y - r.p.y) / r.dir.y;
-    float ty1 = (bmax.y - r.p.y) / r.dir.y;
-    float tz0 = (bmin.z - r.p.z) / r.dir.z;
-    float tz1 = (bmax.z - r.p.z) / r.dir.z;
-    if (tx0 > tx1) { float t = tx1; tx1 = tx0; tx0 = t; }
-    if (ty0 > ty1) { float t = ty1; ty1 = ty0; ty0 = t; }
-    if (tz0 > tz1) { float t = tz1; tz1 = tz0; tz0 = t; }
-    if (r.dir.x == 0) {
-        tEntry = smax(tz0, ty0);
-        tExit = smin(tz1, ty1);
-    } else if (r.dir.y == 0) {
-        tEntry = smax(tz0, tx0);
-        tExit = smin(tz1, tx1);
-    } else if (r.dir.z == 0) {
-        tEntry = smax(ty0, tx0);
-        tExit = smin(ty1, tx1);
-    } else {
-        tEntry = smax(smax(tx0, ty0), tz0);
-        tExit = smin(smin(tx1, ty1), tz1);
+// Wave-aggregated append: every lane with `want` gets a unique index into the level's
+// frame arrays; one atomic per wavefront. Must be reached by all 64 lanes.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
+    unsigned long long mask = __ballot(want);
+    uint32_t base = 0;
+    uint32_t leader = 0;
+    if (mask != 0) {
+        leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     }
-}
-__device__ __forceinline__ bool box_empty(f3 bmin, f3 bmax) {  // Box::IsEmpty, scene.h:85
-    return bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z;
-}
-// Box::IntersectRay(r, t_max) (objFunctions.cpp:143-254)
-__device__ __forceinline__ bool box_hit(const Ray& r, f3 bmin, f3 bmax, float t_max) {
-    if (box_empty(bmin, bmax)) return false;
-    float tEntry, tExit;
-    box_slabs(r, bmin, bmax, tEntry, tExit);
-    return tEntry <= tExit && tEntry < t_max;
-}
-// BVHBoxIntersection (objFunctions.cpp:408-522): tEntry + 0.01 in fp64 (:517), or t_max
-__device__ __forceinline__ float bvh_box(const Ray& r, f3 bmin, f3 bmax) {
-    if (box_empty(bmin, bmax)) return -RTU_BIGFLOAT;
-    float tEntry, tExit;
-    box_slabs(r, bmin, bmax, tEntry, tExit);
-    if (tEntry <= tExit && tEntry < RTU_BIGFLOAT) return (float)((double)tEntry + 0.01);
-    return RTU_BIGFLOAT;
+    base = __shfl(base, (int)leader);
+    unsigned long long below = mask & ((1ull << lane_id()) - 1ull);
+    return base + (uint32_t)__popcll(below);
 }
 
-// ---------------------------------------------------------------------------
-// Sphere::IntersectRay (objFunctions.cpp:15-104), including the stale-z
-// fall-through of the n<m branch. uvw is not produced (no
-// textures on this path).
-__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
-    if (!box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
-    float a = dot3(ray.dir, ray.dir);
-    float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
-    float c = dot3(ray.p, ray.p) - 1;
-    float sqrtCheck = b * b - 4 * a * c;
-    float sq = sqrtf(sqrtCheck);
-    float m = (-b + sq) / (2 * a);
-    float n = (-b - sq) / (2 * a);
-    bool ret = false;
-    if (m == n && m < h.z && (double)m >= 0.001) {
-        h.z = m;
-        h.front = true;
-        ret = true;
-    } else if (m < n && m < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
-        if ((double)m <= 0.001 && (double)n > 0.001 && n < h.z) {
-            h.z = n;
-            h.front = false;
-        } else if ((double)m > 0.001) {
-            h.z = m;
-            h.front = true;
-        }
-        ret = true;
-    } else if (n < m && n < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
-        if ((double)n <= 0.001 && (double)m > 0.001 && m < h.z) {
-            h.z = m;
-            h.front = false;
-        } else if ((double)n > 0.001) {
-            h.z = n;
-            h.front = true;
-        }
-        ret = true;
-    }
-    if (ret) {
-        f3 temp = ray.p + ray.dir * h.z;  // h.z may be stale: reproduced on purpose
-        f3 nn = norm3(temp);
-        h.N = h.front ? nn : -nn;
-        h.p = temp;
-    }
-    return ret;
-}
-
-// Plane::IntersectRay (objFunctions.cpp:107-140)
-__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) {
-    if (!box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
-    if (ray.dir.z != 0) {
-        float t = (-ray.p.z) / (ray.dir.z);
-        if ((double)t > 0.001 && t < h.z) {
-            f3 q = ray.p + ray.dir * t;
-            if (q.x > -1 && q.x < 1 && q.y > -1 && q.y < 1) {
-                h.front = ray.p.z > 0;
-                h.N = mk3(0, 0, h.front ? 1.0f : -1.0f);
-                h.z = t;
-                h.p = mk3(q.x, q.y, 0);
-                return true;
-            }
-        }
-    }
-    return false;
-}
-
-// Point2::Cross (cyPoint.h:247-249)
-__device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return (-ay) * bx + ax * by; }
-
-// cyTriMesh::Interpolate (cyTriMesh.h:191)
-__device__ __forceinline__ f3 interp(const float* arr, const uint32_t* face, f3 bc) {
-    return (ld3(arr + 3 * face[0]) * bc.x + ld3(arr + 3 * face[1]) * bc.y) + ld3(arr + 3 * face[2]) * bc.z;
-}
-
-// TriObj::IntersectTriangle (objFunctions.cpp:257-328) on a pre-gathered triangle
-// record {A,N.x | B,N.y | C,N.z}.
 template <bool STATS>
-__device__ __forceinline__ bool tri_hit(const DevMesh& mesh, uint32_t slot, const Ray& ray, Hit& h, Counters& cnt) {
-    RTU_CNT(tri);
-    float4 r0 = mesh.tri[3 * slot + 0];
-    float4 r1 = mesh.tri[3 * slot + 1];
-    float4 r2 = mesh.tri[3 * slot + 2];
-    f3 A = mk3(r0.x, r0.y, r0.z), B = mk3(r1.x, r1.y, r1.z), C = mk3(r2.x, r2.y, r2.z);
-    f3 N = mk3(r0.w, r1.w, r2.w);
-    float dn = dot3(ray.dir, N);
-    if (dn != 0) {
-        float t = dot3(A - ray.p, N) / dn;
-        if ((double)t > 0.00001 && t < h.z) {
-            f3 q = ray.p + ray.dir * t;
-            float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
-            float maxNormalAxis = smax(smax(anx, any), anz);
-            float ax, ay, bx, by, cx, cy, qx, qy;
-            if (maxNormalAxis == anx) {
-                ax = A.y; ay = A.z; bx = B.y; by = B.z; cx = C.y; cy = C.z; qx = q.y; qy = q.z;
-            } else if (maxNormalAxis == any) {
-                ax = A.x; ay = A.z; bx = B.x; by = B.z; cx = C.x; cy = C.z; qx = q.x; qy = q.z;
-            } else {
-                ax = A.x; ay = A.y; bx = B.x; by = B.y; cx = C.x; cy = C.y; qx = q.x; qy = q.y;
-            }
-            // "/2.0" is evaluated in fp64 in the reference (:298-300); halving is exact in
-            // binary32 as well except when the result is subnormal, so keep the fp64 form.
-            float TriABCArea = (float)((double)cross2(cx - ax, cy - ay, bx - ax, by - ay) / 2.0);
-            float TriAPCArea = (float)((double)cross2(cx - ax, cy - ay, qx - ax, qy - ay) / 2.0);
-            float TriABPArea = (float)((double)cross2(qx - ax, qy - ay, bx - ax, by - ay) / 2.0);
-            float BC1 = TriAPCArea / TriABCArea;
-            float BC2 = TriABPArea / TriABCArea;
-            float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
-            if (BC1 > 0 && BC2 > 0 && BC3 > 0 && BC1 < 1 && BC2 < 1 && BC3 < 1) {
-                RTU_CNT(acc);
-                f3 bc = mk3(BC3, BC1, BC2);
-                uint32_t face = mesh.elements[slot];
-                h.front = dn < 0;
-                h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, bc));
-                h.z = t;
-                h.p = interp(mesh.v, mesh.f + 3 * face, bc);
-                return true;
-            }
-        }
-    }
-    return false;
-}
-
-// TriObj::IntersectRay (objFunctions.cpp:333-406). The reference pushes both
-// children (far first) and pops; popping the near child right after pushing it is
-// the same as continuing with it, so only the far child goes to the LDS stack.
-template <int STACK, bool STATS>
-__device__ __forceinline__ bool mesh_hit(const DevMesh& mesh, const Ray& ray, Hit& h, uint32_t* stk, Counters& cnt) {
-    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
-    RTU_CNT(mesh);
-    bool hitResult = false;
-    int sp = 0;
-    uint32_t cur = 1;  // GetRootNodeID, cyBVH.h:76
-    for (;;) {
-        float4 n0 = mesh.bvh[2 * cur + 0];
-        float4 n1 = mesh.bvh[2 * cur + 1];
-        uint32_t index = __float_as_uint(n0.w), count = __float_as_uint(n1.w);
-        bool pop = true;
-        if (count == 0) {
-            RTU_CNT(inner);
-            uint32_t c1 = index, c2 = index + 1;
-            float4 a0 = mesh.bvh[2 * c1 + 0], a1 = mesh.bvh[2 * c1 + 1];
-            float4 b0 = mesh.bvh[2 * c2 + 0], b1 = mesh.bvh[2 * c2 + 1];
-            float t1 = bvh_box(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
-            float t2 = bvh_box(ray, mk3(b0.x, b0.y, b0.z), mk3(b1.x, b1.y, b1.z));
-            bool v1 = t1 != RTU_BIGFLOAT, v2 = t2 != RTU_BIGFLOAT;
-            // :361-389: (t1 <= t2) push c2 then c1; else push c1 then c2
-            bool firstIsC1 = t1 <= t2;
-            uint32_t nearC = firstIsC1 ? c1 : c2, farC = firstIsC1 ? c2 : c1;
-            bool nearV = firstIsC1 ? v1 : v2, farV = firstIsC1 ? v2 : v1;
-            if (nearV) {
-                if (farV) {
-                    if (sp < STACK) stk[sp * 64] = farC;
-                    sp++;
-                }
-                cur = nearC;
-                pop = false;
-            } else if (farV) {
-                cur = farC;
-                pop = false;
-            }
-        } else {
-            RTU_CNT(leafv);
-            if (STATS) cnt.leafe += count;
-            for (uint32_t i = 0; i < count; i++)  // :394-396
-                hitResult |= tri_hit<STATS>(mesh, index + i, ray, h, cnt);
-        }
-        if (pop) {
-            if (sp == 0) break;
-            sp--;
-            cur = stk[sp * 64];
-        }
-    }
-    return hitResult;
-}
-
-// ---------------------------------------------------------------------------
-// Trace / ShadowTrace (RenderFunctions.cpp:181-240), recursion over the node tree
-// flattened to a pre-order loop. Only h.z (and h.front in the sphere quirk) feeds
-// later intersection tests, so applying FromNodeCoords for the hit node and all of
-// its ancestors immediately is equivalent to the reference applying them as the
-// recursion unwinds.
-//
-// ONE instantiation serves both kinds of ray: `shadow` is a per-lane flag, so
-// lanes casting shadow rays and lanes casting reflection / refraction rays walk
-// the scene together (better SIMD occupancy, a quarter of the code size of four
-// specialised copies — the kernel has to stay inside the instruction cache).
-template <int STACK, bool STATS>
-__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
-    bool any = false;
-    Ray r0 = to_node(s.nodes[0], wr);  // ray inside the root node
-    Ray rp = r0;                       // ray inside node `rp_node` (cached parent space)
-    int rp_node = 0;
-    for (uint32_t k = 0; k < s.n_nodes; k++) {
-        const DevNode& n = s.nodes[k];
-        if (n.obj_type == RTU_OBJ_NONE) continue;
-        if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
-        int parent = n.parent;
-        Ray pr;
-        if (parent < 0) {
-            pr = wr;
-        } else {
-            if (parent != rp_node) {
-                const DevNode& pn = s.nodes[parent];
-                Ray t = r0;
-                for (int d = 1; d <= pn.depth; d++) t = to_node(s.nodes[pn.chain[d]], t);
-                rp = t;
-                rp_node = parent;
-            }
-            pr = rp;
-        }
-        Ray lr = to_node(n, pr);
-        RTU_CNT(node);
-        bool hit;
-        if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h);
-        else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h);
-        else hit = mesh_hit<STACK, STATS>(s.meshes[n.mesh_id], lr, h, stk, cnt);
-        if (hit) {
-            any = true;
-            if (!shadow) {
-                h.node = (int)k;
-                from_node(n, h);
-                for (int j = parent; j >= 0; j = s.nodes[j].parent) from_node(s.nodes[j], h);
-            }
-        }
-    }
-    return any;
-}
-
-// sampledNormal of mtlFunctions.cpp:162-165 / :275-277 with SampleSphere(...,0) == (0,0,0)
-__device__ __forceinline__ f3 sampled_normal(f3 p, f3 N) {
-    f3 sampleOrigin = p + N;
-    return norm3((sampleOrigin + mk3(0, 0, 0)) - p);
-}
-__device__ __forceinline__ f3 reflect_dir(f3 dir, f3 sn) {  // :207, :239, :280
-    float k = 2 * dot3(dir, sn);
-    return norm3(dir - sn * k);
-}
-
-// Snell / Fresnel terms of mtlFunctions.cpp:168-203,236-237. Recomputed from the
-// frame whenever a stage resumes (pure ALU) instead of being saved.
-struct Refr {
-    f3    sn;          // sampled normal
-    float cosTheta1;   // after clamping
-    float sinTheta2, cosTheta2;
-    float n1, n2;
-    f3    SVector;
-};
-__device__ __forceinline__ Refr refraction_terms(f3 dir, f3 p, f3 N, bool front, float ior) {
-    Refr r;
-    r.sn = sampled_normal(p, N);
-    float cosTheta1 = dot3(r.sn, -dir);
-    float sinTheta1 = (float)sqrt(1 - (double)cosTheta1 * (double)cosTheta1);  // :169 (pow(x,2) is exact in fp64)
-    if (sinTheta1 > 1) sinTheta1 = 1.0f;
-    if (sinTheta1 < -1) sinTheta1 = -1.0f;
-    if (cosTheta1 > 1) cosTheta1 = 1.0f;
-    if (cosTheta1 < -1) cosTheta1 = -1.0f;
-    r.cosTheta1 = cosTheta1;
-    r.n1 = ior;
-    r.n2 = 1.0f;
-    if (front) { r.n1 = 1.0f; r.n2 = ior; }
-    r.sinTheta2 = (r.n1 / r.n2) * sinTheta1;
-    r.cosTheta2 = sqrtf(1 - r.sinTheta2 * r.sinTheta2);  // :197
-    if (r.cosTheta2 > 1) r.cosTheta2 = 1.0f;
-    r.SVector = norm3(cross3(r.sn, norm3(cross3(r.sn, -dir))));  // :203
-    return r;
-}
-__device__ __forceinline__ float schlick(const Refr& r) {  // :236-237
-    float q = (r.n1 - r.n2) / (r.n1 + r.n2);
-    float R0 = (float)((double)q * (double)q);
-    double x = 1.0 - (double)r.cosTheta1;
-    double x5 = x * x * x * x * x;  // pow(x,5); affects colour only (tolerance +-1/255)
-    return (float)((double)R0 + (1.0 - (double)R0) * x5);
-}
-__device__ __forceinline__ f3 absorb(float z, f3 absorption) {  // :213-215, :259-261
-    return mk3(expf((-z) * absorption.x), expf((-z) * absorption.y), expf((-z) * absorption.z));
-}
-
-// Stage of a Shade() frame = where the lane resumes.
-enum Stage {
-    ST_PRIMARY = 0,     // fire the primary ray
-    ST_LIGHT,           // direct lighting loop over lights, mtlFunctions.cpp:125-155
-    ST_REFR_START,      // :160
-    ST_TIR_RET,         // child = TIR-reflected hit, :217-221
-    ST_REFR_B_RET,      // child = refracted hit ("refractionResult"), :254
-    ST_REFR_A_RET,      // child = Fresnel-reflected hit ("frenselResult"), :247
-    ST_REFL_START,      // :273
-    ST_REFL_RET,        // child = mirror-reflected hit, :286
-    ST_DONE
-};
-// What the ray in flight is for (decides how its result is consumed).
-enum Pending { P_NONE = 0, P_PRIMARY, P_SHADOW, P_TIR, P_REFR_B, P_REFR_A, P_REFL };
-
-struct Frame {
-    f3    dir, p, N;       // incoming ray direction, hit point, hit normal (world)
-    f3    result;          // partial sum of Shade()
-    f3    term1;           // pending refraction term absV*refr*refractionResult*(1-S)
-    float aux;             // z of the refracted hit (for absorption)
-    int   mtl;             // material id
-    int   bounce;
-    int   stage;
-    bool  front;
-    bool  aux_front;       // front flag of the refracted hit
-};
-
-__device__ __forceinline__ void frame_store(float* arena, uint32_t n_threads, uint32_t tid, int level, const Frame& f) {
-    float* b = arena + (size_t)level * RTU_FRAME_FIELDS * n_threads + tid;
-    const int packed = (f.mtl << 10) | (f.bounce << 6) | (f.stage << 2) | (f.front ? 2 : 0) | (f.aux_front ? 1 : 0);
-    const float v[RTU_FRAME_FIELDS] = {f.dir.x, f.dir.y, f.dir.z, f.p.x, f.p.y, f.p.z, f.N.x, f.N.y, f.N.z,
-                                       f.result.x, f.result.y, f.result.z, f.term1.x, f.term1.y, f.term1.z, f.aux,
-                                       __int_as_float(packed)};
+__device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counters& cnt) {
+    if (!STATS) return;
+    unsigned vals[11] = {cnt.prim, cnt.prim_hit, cnt.sec, cnt.shd, cnt.node, cnt.mesh,
+                         cnt.inner, cnt.leafv, cnt.leafe, cnt.tri, cnt.acc};
 #pragma unroll
-    for (int i = 0; i < RTU_FRAME_FIELDS; i++) b[(size_t)i * n_threads] = v[i];
-}
-__device__ __forceinline__ void frame_load(const float* arena, uint32_t n_threads, uint32_t tid, int level, Frame& f) {
-    const float* b = arena + (size_t)level * RTU_FRAME_FIELDS * n_threads + tid;
-    float v[RTU_FRAME_FIELDS];
+    for (int i = 0; i < 11; i++) {
+        unsigned v = vals[i];
 #pragma unroll
-    for (int i = 0; i < RTU_FRAME_FIELDS; i++) v[i] = b[(size_t)i * n_threads];
-    f.dir = mk3(v[0], v[1], v[2]);
-    f.p = mk3(v[3], v[4], v[5]);
-    f.N = mk3(v[6], v[7], v[8]);
-    f.result = mk3(v[9], v[10], v[11]);
-    f.term1 = mk3(v[12], v[13], v[14]);
-    f.aux = v[15];
-    int packed = __float_as_int(v[16]);
-    f.mtl = packed >> 10;
-    f.bounce = (packed >> 6) & 15;
-    f.stage = (packed >> 2) & 15;
-    f.front = (packed & 2) != 0;
-    f.aux_front = (packed & 1) != 0;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane_id() == 0 && v) atomicAdd(&a.counters[i], (unsigned long long)v);
+    }
 }
 
+// Which rays will this Shade() call fire? Decided once, when the frame is created.
+__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N) {
+    const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
+    uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
+    if (front && s.n_lights > 0) info |= RTU_FI_SH;                      // mtlFunctions.cpp:125
+    if (bounce > 0) {                                                   // :158
+        if (not_black(ld3(m.refraction))) {                             // :160
+            info |= RTU_FI_MAIN;
+            Refr r = refraction_terms(dir, p, N, front, m.ior);
+            if (r.sinTheta2 > 1) info |= RTU_FI_TIR;                    // :205
+        }
+        if (not_black(ld3(m.reflection))) info |= RTU_FI_C;             // :273
+    }
+    return info;
+}
+
+__device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Init, scene.h:162
+    h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
+}
+
+// Direction of secondary ray `slot` of a frame (mtlFunctions.cpp:207, :229, :239, :280).
+__device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 p, f3 N, float ior) {
+    if (slot == SLOT_C) return reflect_dir(dir, sampled_normal(p, N));
+    Refr t = refraction_terms(dir, p, N, (info & RTU_FI_FRONT) != 0, ior);
+    if (slot == SLOT_A || (info & RTU_FI_TIR)) return reflect_dir(dir, t.sn);
+    return norm3((-t.sn) * t.cosTheta2 + t.SVector * t.sinTheta2);
+}
+
+// ------------------------------------------------------------------------------------
 template <int STACK, bool STATS>
-__global__ void __launch_bounds__(64) render_kernel(KernelArgs a) {
+__global__ void __launch_bounds__(64) k_primary(KernelArgs a) {
     __shared__ uint32_t s_stack[STACK * 64];
     const DevScene& s = a.scene;
     const uint32_t lane = threadIdx.x;
@@ -453,252 +114,337 @@ __global__ void __launch_bounds__(64) render_kernel(KernelArgs a) {
     const int x = (int)(tx * 8 + (lane & 7));
     const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
     const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
-    uint32_t* stk = s_stack + lane;
-    const uint32_t tid = blockIdx.x * 64 + lane;
-    Counters cnt = {};
     const bool valid = x < a.frame.width && y < a.frame.height;
-    const f3 cam_pos = ld3(a.frame.cam_pos);
-    const f3 env = ld3(s.environment);
-
-    // ---- per-lane state of the explicit Shade() recursion -------------------------
-    Frame F;
-    F.dir = F.p = F.N = F.result = F.term1 = mk3(0, 0, 0);
-    F.aux = 0; F.mtl = 0; F.bounce = 0; F.front = true; F.aux_front = true;
-    F.stage = ST_PRIMARY;
-    int level = 0;
-    uint32_t li = 0;             // next light of the ST_LIGHT loop
-    f3 ret = mk3(0, 0, 0);       // value returned by the child frame that just finished
-    f3 color = mk3(0, 0, 0);     // final pixel colour
-    float zprim = RTU_BIGFLOAT;  // hInfo.z of the primary ray
-    f3 lightK = mk3(0, 0, 0);    // diffuse + specular*pow(N.H, gloss) of the light whose shadow ray is in flight
-    float lightNDotL = 0;
-    bool fin = !valid;
-
-    while (!fin) {
-        // ======== phase A: run the lane's frame until it needs a ray (or finishes) ========
-        int pend = P_NONE;
-        Ray nr;
-        nr.p = F.p; nr.dir = mk3(0, 0, 0);
-        float tmax = RTU_BIGFLOAT;
-        while (pend == P_NONE && !fin) {
-            if (F.stage == ST_PRIMARY) {
-                // RenderFunctions.cpp:258-268 (pixel centre), :97
-                f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
-                nr.p = cam_pos;
-                nr.dir = norm3(cp - cam_pos);
-                RTU_CNT(prim);
-                pend = P_PRIMARY;
-            } else if (F.stage == ST_LIGHT) {
-                if (!F.front || li >= s.n_lights) {  // :125 only front faces are lit
-                    F.stage = ST_REFR_START;
-                    continue;
-                }
-                const RtuLight& l = s.lights[li];
-                const RtuMaterial& m = s.materials[F.mtl];
-                f3 intensity = ld3(l.intensity);
-                f3 diffuse = ld3(m.diffuse);
-                if (l.type == RTU_LIGHT_AMBIENT) {
-                    F.result = F.result + diffuse * intensity;  // :132
-                    li++;
-                    continue;
-                }
-                f3 viewDirection = norm3(cam_pos - F.p);  // :137
-                f3 lvec = ld3(l.vec);
-                bool isDirect = l.type == RTU_LIGHT_DIRECT;
-                f3 ldir = isDirect ? lvec : norm3(F.p - lvec);          // Direction(), lights.h:49,83
-                f3 lightDirection = norm3(-ldir);                      // :138
-                f3 halfVector = norm3(viewDirection + lightDirection);  // :139
-                float NDotL = dot3(F.N, lightDirection);
-                float NDotH = dot3(F.N, halfVector);
-                if (NDotL < 0.0f) NDotL = 0.0f;
-                if (NDotH < 0.0f) NDotH = 0.0f;
-                lightNDotL = NDotL;
-                lightK = diffuse + ld3(m.specular) * powf(NDotH, m.glossiness);  // :152
-                nr.p = F.p;
-                if (isDirect) {
-                    nr.dir = -lvec;  // lights.h:48
-                    tmax = RTU_BIGFLOAT;
-                } else {
-                    nr.dir = norm3(lvec - F.p);  // lightFunctions.cpp:76
-                    tmax = len3(lvec - F.p);     // :78
-                }
-                RTU_CNT(shd);
-                pend = P_SHADOW;
-            } else if (F.stage == ST_REFR_START) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                if (F.bounce > 0 && not_black(ld3(m.refraction))) {
-                    Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                    if (r.sinTheta2 > 1) {  // total internal reflection, :205
-                        nr.dir = reflect_dir(F.dir, r.sn);
-                        pend = P_TIR;
-                    } else {
-                        nr.dir = norm3((-r.sn) * r.cosTheta2 + r.SVector * r.sinTheta2);  // :229
-                        pend = P_REFR_B;
-                    }
-                    nr.p = F.p;
-                    RTU_CNT(sec);
-                } else {
-                    F.stage = (F.bounce > 0) ? ST_REFL_START : ST_DONE;
-                }
-            } else if (F.stage == ST_TIR_RET) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                f3 absorptionV = absorb(RTU_BIGFLOAT, ld3(m.absorption));  // z of a fresh HitInfo, :210-215
-                F.result = F.result + absorptionV * ret;                    // :219-221
-                F.stage = ST_REFL_START;
-            } else if (F.stage == ST_REFR_B_RET) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                float S = schlick(r);
-                f3 absorptionV = mk3(1, 1, 1);
-                if (!F.aux_front) absorptionV = absorb(F.aux, ld3(m.absorption));  // :258-262
-                F.term1 = ((absorptionV * ld3(m.refraction)) * ret) * (float)(1.0 - (double)S);
-                nr.p = F.p;
-                nr.dir = reflect_dir(F.dir, r.sn);  // Fresnel reflection ray, :239
-                RTU_CNT(sec);
-                pend = P_REFR_A;
-            } else if (F.stage == ST_REFR_A_RET) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                float S = schlick(r);
-                f3 frenselResult = ld3(m.refraction) * ret;           // :247
-                F.result = F.result + (F.term1 + frenselResult * S);  // :264
-                F.stage = ST_REFL_START;
-            } else if (F.stage == ST_REFL_START) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                if (not_black(ld3(m.reflection))) {  // :273 (bounce > 0 is implied by reaching this stage)
-                    f3 sn = sampled_normal(F.p, F.N);
-                    nr.p = F.p;
-                    nr.dir = reflect_dir(F.dir, sn);  // :280
-                    RTU_CNT(sec);
-                    pend = P_REFL;
-                } else {
-                    F.stage = ST_DONE;
-                }
-            } else if (F.stage == ST_REFL_RET) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                F.result = F.result + ld3(m.reflection) * ret;  // :286
-                F.stage = ST_DONE;
-            } else {  // ST_DONE: return to the caller frame
-                ret = F.result;
-                if (level == 0) {
-                    color = ret;
-                    fin = true;
-                } else {
-                    level--;
-                    frame_load(a.arena, a.n_threads, tid, level, F);
-                }
-            }
-        }
-        if (fin) break;
-
-        // ======== phase B: the one ray-scene intersection site of the kernel ========
-        Hit h;
-        h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
-        const bool is_shadow = pend == P_SHADOW;
-        const bool hit = trace<STACK, STATS>(s, nr, is_shadow, h, stk, cnt);
-
-        // ======== phase C: consume the result ========
-        if (is_shadow) {
-            // GenLight::Shadow (lightFunctions.cpp:27-37) + Illuminate (lights.h:48, lightFunctions.cpp:75-83)
-            float sh = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
-            const RtuLight& l = s.lights[li];
-            f3 intensity = ld3(l.intensity);
-            f3 illum;
-            if (l.type == RTU_LIGHT_DIRECT) {
-                illum = intensity * sh;
-            } else {
-                f3 d = ld3(l.vec) - F.p;
-                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // :83
-            }
-            F.result = F.result + (illum * lightNDotL) * lightK;  // mtlFunctions.cpp:152
-            li++;
-        } else if (pend == P_PRIMARY) {
-            zprim = h.z;
-            if (!hit) {
-                color = ld3(s.background);  // RenderFunctions.cpp:145
-                fin = true;
-            } else {
-                RTU_CNT(prim_hit);
-                int mid = s.nodes[h.node].material_id;
-                if (mid < 0) {
-                    color = mk3(1, 1, 1);  // null material => white
-                    fin = true;
-                } else {
-                    F.dir = nr.dir; F.p = h.p; F.N = h.N; F.front = h.front;
-                    F.mtl = mid; F.bounce = a.frame.max_bounce;
-                    F.result = mk3(0, 0, 0);
-                    F.stage = ST_LIGHT;
-                    li = 0;
-                }
-            }
-        } else if (hit) {
-            // a secondary ray hit: Shade() of the hit node becomes the active frame
-            int ret_stage = pend == P_TIR ? ST_TIR_RET : pend == P_REFR_B ? ST_REFR_B_RET : pend == P_REFR_A ? ST_REFR_A_RET : ST_REFL_RET;
-            if (pend == P_REFR_B) { F.aux = h.z; F.aux_front = h.front; }
-            F.stage = ret_stage;
-            int cmid = s.nodes[h.node].material_id;
-            if (cmid < 0) {
-                ret = mk3(1, 1, 1);  // null material (the reference would crash here)
-            } else {
-                frame_store(a.arena, a.n_threads, tid, level, F);
-                level++;
-                int cb = F.bounce - 1;
-                F.dir = nr.dir; F.p = h.p; F.N = h.N; F.front = h.front;
-                F.mtl = cmid; F.bounce = cb;
-                F.result = mk3(0, 0, 0); F.term1 = mk3(0, 0, 0); F.aux = 0; F.aux_front = true;
-                F.stage = ST_LIGHT;
-                li = 0;
-            }
+    Counters cnt = {};
+    bool want = false;
+    Hit h;
+    fresh_hit(h, RTU_BIGFLOAT);
+    Ray ray;
+    ray.p = ld3(a.frame.cam_pos);
+    ray.dir = mk3(0, 0, 0);
+    int mid = -1;
+    const uint32_t pix = (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+    if (valid) {
+        // RenderFunctions.cpp:258-268 (pixel centre), :97
+        f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
+        ray.dir = norm3(cp - ray.p);
+        RTU_CNT(prim);
+        bool hit = trace<STACK, STATS, !STATS>(s, ray, false, h, s_stack + lane, cnt);
+        if (!hit) {
+            f3 bg = ld3(s.background);  // :145
+            a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
         } else {
-            // a secondary ray missed
-            if (pend == P_TIR) {
-                F.stage = ST_REFL_START;  // :217 has no else branch
-            } else if (pend == P_REFR_B) {
-                F.result = F.result + env;  // :267
-                F.stage = ST_REFL_START;
-            } else if (pend == P_REFR_A) {
-                const RtuMaterial& m = s.materials[F.mtl];
-                Refr r = refraction_terms(F.dir, F.p, F.N, F.front, m.ior);
-                float S = schlick(r);
-                F.result = F.result + (F.term1 + env * S);  // :250, :264
-                F.stage = ST_REFL_START;
-            } else {
-                const RtuMaterial& m = s.materials[F.mtl];
-                F.result = F.result + env * ld3(m.reflection);  // :289
-                F.stage = ST_DONE;
-            }
+            RTU_CNT(prim_hit);
+            mid = as_const(s.nodes)[h.node].material_id;
+            if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
+            else want = true;
         }
     }
+    uint32_t idx = wave_append(&a.fcnt->n_frames[0], want);
+    if (want) {
+        const LevelBuffers& lv = a.lv[0];
+        if (idx < lv.cap) {
+            uint32_t info = make_info(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N);
+            lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
+            lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
+            lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
+        } else {
+            a.fcnt->overflow = 1;
+        }
+    }
+    flush_counters<STATS>(a, cnt);
+}
 
-    if (valid) a.out[(size_t)ly * a.frame.width + x] = make_float4(color.x, color.y, color.z, zprim);
+// ------------------------------------------------------------------------------------
+// One lane = one ray of one frame. Work is laid out slot-major in chunks of 64 frames.
+template <int STACK, bool STATS>
+__global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel) {
+    __shared__ uint32_t s_stack[STACK * 64];
+    const DevScene& s = a.scene;
+    const LevelBuffers& lv = a.lv[L];
+    const uint32_t lane = threadIdx.x;
+    uint32_t n = a.fcnt->n_frames[L];
+    if (n > lv.cap) n = lv.cap;
+    const uint32_t chunks = (n + 63u) / 64u;
+    const uint32_t nslots = a.nsl + 3u;
+    const uint32_t total = chunks * nslots;
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
+        const uint32_t slot = c / chunks;
+        const uint32_t f = (c - slot * chunks) * 64u + lane;
+        if (f >= n) continue;
+        const float4 fa = lv.fa[f];
+        const uint32_t info = __float_as_uint(fa.w);
+        const f3 p = mk3(fa.x, fa.y, fa.z);
+        if (slot < a.nsl) {
+            // ---- shadow ray of non-ambient light `slot` (lightFunctions.cpp:27-37, 75-78; lights.h:48)
+            if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) continue;
+            const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[slot]];
+            f3 lvec = ld3(l.vec);
+            Ray r;
+            r.p = p;
+            float tmax;
+            if (l.type == RTU_LIGHT_DIRECT) {
+                r.dir = -lvec;
+                tmax = RTU_BIGFLOAT;
+            } else {
+                r.dir = norm3(lvec - p);
+                tmax = len3(lvec - p);
+            }
+            RTU_CNT(shd);
+            Hit h;
+            fresh_hit(h, tmax);
+            bool hit = trace<STACK, STATS, !STATS>(s, r, true, h, s_stack + lane, cnt);
+            lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
+        } else {
+            // ---- secondary rays of MtlBlinn::Shade (mtlFunctions.cpp:160-229, 239, 273-283)
+            const int sslot = (int)(slot - a.nsl);
+            if (sslot == SLOT_MAIN && (!(sel & SEL_MAIN) || !(info & RTU_FI_MAIN))) continue;
+            if (sslot == SLOT_A && (!(sel & SEL_A) || !(info & RTU_FI_MAIN) || (info & RTU_FI_TIR))) continue;
+            if (sslot == SLOT_C && (!(sel & SEL_C) || !(info & RTU_FI_C))) continue;
+            if (sslot == SLOT_A && (sel & SEL_A_NEEDS_B)) {
+                // counting variant: the Fresnel ray exists only if the refracted ray hit (:234)
+                const float4 b1 = lv.fslot[((size_t)f * 3 + SLOT_MAIN) * 2 + 1];
+                if (!(__float_as_uint(b1.w) & 1u)) continue;
+            }
+            const float4 fb = lv.fb[f], fc = lv.fc[f];
+            const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+            const float ior = as_const(s.materials)[info & RTU_FI_MTL_MASK].ior;
+            Ray r;
+            r.p = p;
+            r.dir = secondary_dir(sslot, info, dir, p, N, ior);
+            RTU_CNT(sec);
+            Hit h;
+            fresh_hit(h, RTU_BIGFLOAT);
+            bool hit = trace<STACK, STATS, !STATS>(s, r, false, h, s_stack + lane, cnt);
+            int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
+            // packed: bit0 hit, bit1 front, bits 2.. material id + 1 (0 = node without material)
+            uint32_t packed = (hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2);
+            float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
+            slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+            slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
+        }
+    }
+    flush_counters<STATS>(a, cnt);
+}
 
-    if (STATS) {
-        // wave reduction, then one atomic per counter per wave
-        unsigned vals[11] = {cnt.prim, cnt.prim_hit, cnt.sec, cnt.shd, cnt.node, cnt.mesh,
-                             cnt.inner, cnt.leafv, cnt.leafe, cnt.tri, cnt.acc};
+// ------------------------------------------------------------------------------------
+// MtlBlinn::Shade combination (mtlFunctions.cpp:205-291) once every child result is
+// known. st* >= 0 or RTU_CH_WHITE: that ray hit and ret* holds Shade() of the hit.
+__device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMaterial& m, uint32_t info, f3 direct, f3 dir, f3 p,
+                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront) {
+    const f3 env = ld3(s.environment);
+    const bool front = (info & RTU_FI_FRONT) != 0;
+    f3 result = direct;
+    if (info & RTU_FI_MAIN) {
+        const f3 refraction = ld3(m.refraction), absorption = ld3(m.absorption);
+        const bool mainHit = stMain >= 0 || stMain == RTU_CH_WHITE;
+        if (info & RTU_FI_TIR) {
+            if (mainHit) result = result + absorb(RTU_BIGFLOAT, absorption) * retMain;  // :210-221 (z of a fresh HitInfo)
+        } else if (mainHit) {
+            Refr r = refraction_terms(dir, p, N, front, m.ior);
+            float S = schlick(r);                                                        // :236-237
+            f3 absorptionV = mk3(1, 1, 1);
+            if (!bfront) absorptionV = absorb(bz, absorption);                           // :258-262
+            f3 term1 = ((absorptionV * refraction) * retMain) * (float)(1.0 - (double)S);
+            const bool aHit = stA >= 0 || stA == RTU_CH_WHITE;
+            f3 frenselResult = aHit ? refraction * retA : env;                           // :247 / :250
+            result = result + (term1 + frenselResult * S);                               // :264
+        } else {
+            result = result + env;                                                       // :267
+        }
+    }
+    if (info & RTU_FI_C) {
+        const f3 reflection = ld3(m.reflection);
+        const bool cHit = stC >= 0 || stC == RTU_CH_WHITE;
+        if (cHit) result = result + reflection * retC;                                   // :286
+        else result = result + env * reflection;                                         // :289
+    }
+    return result;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
+    const DevScene& s = a.scene;
+    const LevelBuffers& lv = a.lv[L];
+    const bool haveNext = L + 1 < RTU_MAX_LEVELS;
+    const int Ln = haveNext ? L + 1 : L;
+    const LevelBuffers& nx = a.lv[Ln];
+    const uint32_t lane = threadIdx.x;
+    uint32_t n = a.fcnt->n_frames[L];
+    if (n > lv.cap) n = lv.cap;
+    const f3 cam_pos = ld3(a.frame.cam_pos);
+    const uint32_t chunks = (n + 63u) / 64u;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t f = c * 64u + lane;
+        const bool active = f < n;
+        float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
+        if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
+        const uint32_t info = __float_as_uint(fa.w);
+        const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+        const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
+        const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
+
+        // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
+        f3 direct = mk3(0, 0, 0);
+        if (active && (info & RTU_FI_SH)) {
+            const f3 diffuse = ld3(m.diffuse), specular = ld3(m.specular);
+            uint32_t j = 0;  // index among the non-ambient lights
+            for (uint32_t i = 0; i < s.n_lights; i++) {
+                const RTU_CONST RtuLight& l = as_const(s.lights)[i];
+                const f3 intensity = ld3(l.intensity);
+                if (l.type == RTU_LIGHT_AMBIENT) {
+                    direct = direct + diffuse * intensity;  // :132
+                    continue;
+                }
+                const f3 viewDirection = norm3(cam_pos - p);  // :137
+                const f3 lvec = ld3(l.vec);
+                const bool isDirect = l.type == RTU_LIGHT_DIRECT;
+                const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
+                const f3 lightDirection = norm3(-ldir);                       // :138
+                const f3 halfVector = norm3(viewDirection + lightDirection);  // :139
+                float NDotL = dot3(N, lightDirection);
+                float NDotH = dot3(N, halfVector);
+                if (NDotL < 0.0f) NDotL = 0.0f;
+                if (NDotH < 0.0f) NDotH = 0.0f;
+                const float sh = lv.fsh[(size_t)f * a.nsl + j];
+                j++;
+                f3 illum;
+                if (isDirect) {
+                    illum = intensity * sh;  // lights.h:48
+                } else {
+                    const f3 d = lvec - p;
+                    illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
+                }
+                direct = direct + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
+            }
+        }
+
+        // ---- secondary-ray hits become frames of the next level ----
+        int st[3] = {RTU_CH_NONE, RTU_CH_NONE, RTU_CH_NONE};
+        float bz = 0.0f;
+        bool bfront = true;
 #pragma unroll
-        for (int i = 0; i < 11; i++) {
-            unsigned v = vals[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && v) atomicAdd(&a.counters[i], (unsigned long long)v);
+        for (int k = 0; k < 3; k++) {
+            bool slotActive = false;
+            if (active) {
+                if (k == SLOT_MAIN) slotActive = (info & RTU_FI_MAIN) != 0;
+                else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (st[SLOT_MAIN] >= 0 || st[SLOT_MAIN] == RTU_CH_WHITE);
+                else slotActive = (info & RTU_FI_C) != 0;
+            }
+            float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+            uint32_t packed = 0;
+            if (slotActive) {
+                const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
+                s0 = slotp[0];
+                s1 = slotp[1];
+                packed = __float_as_uint(s1.w);
+            }
+            const bool hit = slotActive && (packed & 1u);
+            const int cmid = (int)(packed >> 2) - 1;
+            const bool spawn = hit && cmid >= 0 && haveNext;
+            if (k == SLOT_MAIN && hit) { bz = s0.w; bfront = (packed & 2u) != 0; }
+            const uint32_t idx = wave_append(&a.fcnt->n_frames[Ln], spawn);  // all 64 lanes take part
+            if (!slotActive) continue;
+            if (!hit) st[k] = RTU_CH_MISS;
+            else if (cmid < 0) st[k] = RTU_CH_WHITE;
+            else if (spawn && idx < nx.cap) {
+                // the child Shade(): ray direction, hit point and normal of the secondary ray
+                const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
+                const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
+                const uint32_t cinfo = make_info(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN);
+                nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
+                nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
+                nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0.w);
+                st[k] = (int)idx;
+            } else {
+                a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
+                st[k] = RTU_CH_MISS;
+            }
+        }
+        if (!active) continue;
+        const bool pending = st[0] >= 0 || st[1] >= 0 || st[2] >= 0;
+        if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
+        if (!pending) {
+            const f3 one = mk3(1, 1, 1);
+            const f3 r = finalize(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront);
+            if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+            else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+        } else {
+            lv.fres[f] = make_float4(direct.x, direct.y, direct.z, 0.0f);  // the direct term waits for the children
         }
     }
 }
 
+// Frames that waited for children: combine bottom-up.
+__global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
+    const DevScene& s = a.scene;
+    const LevelBuffers& lv = a.lv[L];
+    const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
+    uint32_t n = a.fcnt->n_frames[L];
+    if (n > lv.cap) n = lv.cap;
+    const uint32_t chunks = (n + 63u) / 64u;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t f = c * 64u + threadIdx.x;
+        if (f >= n) continue;
+        const float4 fa = lv.fa[f];
+        const uint32_t info = __float_as_uint(fa.w);
+        if (!(info & (RTU_FI_MAIN | RTU_FI_C))) continue;  // never had secondary rays
+        const int4 ch = lv.fchild[f];
+        if (!ch.w) continue;                                // already final
+        const float4 fb = lv.fb[f], fc = lv.fc[f], fr = lv.fres[f];
+        const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+        const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
+        const int st[3] = {ch.x, ch.y, ch.z};
+        f3 ret[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ret[k] = mk3(1, 1, 1);
+            if (st[k] >= 0) {
+                const float4 r = nx.fres[st[k]];
+                ret[k] = mk3(r.x, r.y, r.z);
+            }
+        }
+        float bz = 0.0f;
+        bool bfront = true;
+        if ((info & RTU_FI_MAIN) && !(info & RTU_FI_TIR)) {
+            const float4* slotp = lv.fslot + ((size_t)f * 3 + SLOT_MAIN) * 2;
+            bz = slotp[0].w;
+            bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
+        }
+        const f3 r = finalize(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront);
+        if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+        else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+    }
+}
+
+template <int STACK>
+int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
+    const int levels = a.frame.max_bounce + 1;
+    const dim3 block(64);
+    const dim3 gridT(16384), gridF(4096);  // persistent grids: 64-frame chunks are strided over them
+    if (n_tiles == 0) return (int)hipSuccess;
+    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(n_tiles), block, 0, stream, a);
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(n_tiles), block, 0, stream, a);
+    for (int L = 0; L < levels; L++) {
+        if (stats) {
+            hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C));
+            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B));
+            hipLaunchKernelGGL((k_consume<true>), gridF, block, 0, stream, a, L);
+        } else {
+            hipLaunchKernelGGL((k_trace<STACK, false>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C));
+            hipLaunchKernelGGL((k_consume<false>), gridF, block, 0, stream, a, L);
+        }
+    }
+    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL(k_combine, gridF, block, 0, stream, a, L);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
-int rtu_launch_render(const KernelArgs& args, uint32_t n_blocks, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
-    if (n_blocks == 0) return (int)hipSuccess;
-    dim3 grid(n_blocks), block(64);
-#define RTU_LAUNCH(S)                                                                               \
-    do {                                                                                            \
-        if (stats) hipLaunchKernelGGL((render_kernel<S, true>), grid, block, 0, stream, args);      \
-        else hipLaunchKernelGGL((render_kernel<S, false>), grid, block, 0, stream, args);           \
-    } while (0)
-    if (bvh_stack_needed <= 16) RTU_LAUNCH(16);
-    else if (bvh_stack_needed <= 32) RTU_LAUNCH(32);
-    else RTU_LAUNCH(RTU_MAX_BVH_STACK);
-#undef RTU_LAUNCH
-    return (int)hipGetLastError();
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
+    if (bvh_stack_needed <= 16) return launch_all<16>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 24) return launch_all<24>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 32) return launch_all<32>(args, n_tiles, stats, stream);
+    return launch_all<RTU_MAX_BVH_STACK>(args, n_tiles, stats, stream);
 }

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,8 +25,14 @@ struct RtuContext {
     uint32_t bvh_stack_needed = 1;
 
     // per-frame resources (grown on demand, reused)
-    float*  arena = nullptr;
-    size_t  arena_bytes = 0;
+    std::vector<void*> level_allocs;
+    LevelBuffers lv[RTU_MAX_LEVELS] = {};
+    uint32_t level_cap0 = 0;        // pixels the level buffers were sized for
+    uint32_t level_nsl = 0;
+    uint32_t cap_scale = 1;         // capacity of levels >= 1 = cap_scale * pixels (doubled on overflow)
+    FrameCounters* fcnt = nullptr;
+    uint32_t nsl = 0;
+    int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
     unsigned long long* counters = nullptr;  // 11 x u64
@@ -75,7 +82,6 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
     if (s->n_materials && !s->materials) return fail(ctx, RTU_ERR_ARG, "materials is NULL");
     if (s->n_lights && !s->lights) return fail(ctx, RTU_ERR_ARG, "lights is NULL");
     if (s->n_meshes && !s->meshes) return fail(ctx, RTU_ERR_ARG, "meshes is NULL");
-    if (s->n_materials >= (1u << 20)) return fail(ctx, RTU_ERR_UNSUPPORTED, "too many materials");
     if (s->camera.dof != 0) return fail(ctx, RTU_ERR_STOCHASTIC, "depth of field is stochastic");
     if ((s->background.has_map && !s->background.map_is_null) || (s->environment.has_map && !s->environment.map_is_null))
         return fail(ctx, RTU_ERR_UNSUPPORTED, "textured background/environment");
@@ -84,6 +90,11 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
         if (l.type < RTU_LIGHT_AMBIENT || l.type > RTU_LIGHT_POINT) return fail(ctx, RTU_ERR_ARG, "light %u: bad type", i);
         if (l.type == RTU_LIGHT_POINT && l.size > 0) return fail(ctx, RTU_ERR_STOCHASTIC, "light %u: soft shadow", i);
     }
+    uint32_t n_shadow = 0;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT) n_shadow++;
+    if (n_shadow > RTU_MAX_SHADOW_LIGHTS) return fail(ctx, RTU_ERR_UNSUPPORTED, "more than %d non-ambient lights", RTU_MAX_SHADOW_LIGHTS);
+    if (s->n_materials > RTU_FI_MTL_MASK) return fail(ctx, RTU_ERR_UNSUPPORTED, "too many materials");
     for (uint32_t i = 0; i < s->n_materials; i++)
         if (s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0)
             return fail(ctx, RTU_ERR_STOCHASTIC, "material %u: glossy bounce", i);
@@ -104,6 +115,7 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
         if (!m.v || !m.f || !m.vn || !m.fn || !m.bvh || !m.elements)
             return fail(ctx, RTU_ERR_ARG, "mesh %u: missing array (normals are required, objects.h:56)", mi);
         if (m.n_bvh_nodes < 2 || m.n_elements != m.nf || m.nf == 0) return fail(ctx, RTU_ERR_ARG, "mesh %u: empty", mi);
+        if (m.n_bvh_nodes >= (1u << 28) || m.n_elements >= (1u << 28)) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: more than 2^28 nodes/elements", mi);
         if (m.bvh_depth > RTU_MAX_BVH_STACK) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: BVH depth %u > %d", mi, m.bvh_depth, RTU_MAX_BVH_STACK);
         for (uint32_t i = 0; i < m.nf * 3; i++) {
             if (m.f[i] >= m.nv) return fail(ctx, RTU_ERR_ARG, "mesh %u: vertex index out of range", mi);
@@ -154,31 +166,77 @@ int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
     return RTU_OK;
 }
 
+void free_levels(RtuContext* ctx) {
+    for (void* p : ctx->level_allocs) (void)hipFree(p);
+    ctx->level_allocs.clear();
+    memset(ctx->lv, 0, sizeof ctx->lv);
+    ctx->level_cap0 = 0;
+}
+
+template <class T>
+int alloc_level(RtuContext* ctx, T** dst, size_t count) {
+    void* d = nullptr;
+    RTU_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+    ctx->level_allocs.push_back(d);
+    *dst = static_cast<T*>(d);
+    return RTU_OK;
+}
+
+// Frame arrays of every recursion level (rtu_device.h). Level 0 holds at most one
+// frame per pixel; deeper levels get cap_scale * pixels and are grown on overflow.
+int ensure_levels(RtuContext* ctx, uint32_t pixels) {
+    if (ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && ctx->lv[1].cap >= ctx->cap_scale * pixels) return RTU_OK;
+    free_levels(ctx);
+    int rc;
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        LevelBuffers& lv = ctx->lv[L];
+        size_t cap = L == 0 ? pixels : (size_t)pixels * ctx->cap_scale;
+        if (cap > 0x7FFFFFF0u) return fail(ctx, RTU_ERR_UNSUPPORTED, "frame capacity overflow");
+        if ((rc = alloc_level(ctx, &lv.fa, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fb, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fc, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fres, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fchild, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
+        lv.cap = (uint32_t)cap;
+    }
+    ctx->level_cap0 = pixels;
+    ctx->level_nsl = ctx->nsl;
+    return RTU_OK;
+}
+
 int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
     uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
     uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
-    uint32_t n_blocks = tiles_x * bands;
-    uint32_t n_threads = n_blocks * 64;
-    size_t need = (size_t)n_threads * RTU_FRAME_FIELDS * sizeof(float) * (size_t)(frame->max_bounce > 0 ? frame->max_bounce : 1);
-    if (need > ctx->arena_bytes) {
-        if (ctx->arena) (void)hipFree(ctx->arena);
-        ctx->arena = nullptr;
-        ctx->arena_bytes = 0;
-        RTU_HIP(ctx, hipMalloc((void**)&ctx->arena, need));
-        ctx->arena_bytes = need;
-    }
+    uint32_t n_tiles = tiles_x * bands;
+    uint32_t pixels = (uint32_t)rtu_shard_rows(frame) * (uint32_t)frame->width;
+    int rc = ensure_levels(ctx, pixels);
+    if (rc != RTU_OK) return rc;
     bool stats = frame->collect_stats != 0;
     if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
+    RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, sizeof(FrameCounters), stream));
     KernelArgs a;
+    memset(&a, 0, sizeof a);
     a.scene = ctx->dscene;
     a.frame = *frame;
     a.out = d_out;
-    a.arena = ctx->arena;
+    memcpy(a.lv, ctx->lv, sizeof a.lv);
+    a.fcnt = ctx->fcnt;
     a.counters = stats ? ctx->counters : nullptr;
     a.tiles_x = tiles_x;
-    a.n_threads = n_threads;
-    hipError_t e = (hipError_t)rtu_launch_render(a, n_blocks, ctx->bvh_stack_needed, stats, stream);
+    a.nsl = ctx->nsl;
+    memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
+    hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
+// After the stream has drained: did any recursion level run out of frame capacity?
+int check_overflow(RtuContext* ctx, bool* overflow) {
+    FrameCounters h;
+    RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
+    *overflow = h.overflow != 0;
     return RTU_OK;
 }
 
@@ -201,6 +259,7 @@ const char* rtu_error_string(int err) {
         case RTU_ERR_STOCHASTIC: return "scene uses a stochastic feature";
         case RTU_ERR_NO_SCENE: return "no scene uploaded";
         case RTU_ERR_NO_DEVICE: return "no such GPU";
+        case RTU_ERR_CAPACITY: return "recursion frame capacity exceeded";
     }
     return "unknown error";
 }
@@ -217,6 +276,8 @@ RtuContext* rtu_create_context(int device_id, int* err_out) {
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc((void**)&ctx->counters, 11 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&ctx->fcnt, sizeof(FrameCounters)) == hipSuccess &&
+              hipMemset(ctx->fcnt, 0, sizeof(FrameCounters)) == hipSuccess &&
               hipMemset(ctx->counters, 0, 11 * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         if (err_out) *err_out = RTU_ERR_HIP;
@@ -232,7 +293,8 @@ void rtu_destroy_context(RtuContext* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
-    if (ctx->arena) (void)hipFree(ctx->arena);
+    free_levels(ctx);
+    if (ctx->fcnt) (void)hipFree(ctx->fcnt);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -315,6 +377,10 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     env_value(s->background, ds.background);
     env_value(s->environment, ds.environment);
     ctx->dscene = ds;
+    ctx->nsl = 0;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
+    ctx->cap_scale = 1;
     ctx->bvh_stack_needed = stack_needed;
     ctx->has_scene = true;
     return RTU_OK;
@@ -407,11 +473,32 @@ int rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, 
     }
     RtuFrameDesc f = *frame;
     if (stats) f.collect_stats = 1;
-    rc = launch(ctx, &f, ctx->fb, ctx->stream, true);
-    if (rc != RTU_OK) return rc;
-    if (bytes) RTU_HIP(ctx, hipMemcpyAsync(h_rgbz, ctx->fb, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int attempt = 0;; attempt++) {
+        rc = launch(ctx, &f, ctx->fb, ctx->stream, true);
+        if (rc != RTU_OK) return rc;
+        RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool overflow = false;
+        if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
+        if (!overflow) break;
+        if (attempt >= 4) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceed %ux the pixel count", ctx->cap_scale);
+        ctx->cap_scale *= 2;  // more frames than provisioned: grow the level arrays and render again
+    }
+    if (bytes) RTU_HIP(ctx, hipMemcpy(h_rgbz, ctx->fb, bytes, hipMemcpyDeviceToHost));
     if (stats) return rtu_get_stats(ctx, stats);
+    return RTU_OK;
+}
+
+int rtu_frame_status(RtuContext* ctx) {
+    if (!ctx) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    bool overflow = false;
+    int rc = check_overflow(ctx, &overflow);
+    if (rc != RTU_OK) return rc;
+    if (overflow) {
+        ctx->cap_scale *= 2;  // the next frame is rendered with twice the capacity
+        return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity; render the frame again");
+    }
     return RTU_OK;
 }
 

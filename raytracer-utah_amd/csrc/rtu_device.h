@@ -17,6 +17,17 @@
 #include "rtu_render.h"
 #include "rtu_vec.h"
 
+// Wave-uniform scene data (nodes, lights, materials, mesh headers) is read through
+// the CONSTANT address space so the compiler emits scalar loads (s_load) into SGPRs
+// instead of 64 identical vector loads.
+#define RTU_CONST __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ const RTU_CONST T* as_const(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const RTU_CONST T*)(p);
+#pragma clang diagnostic pop
+}
+
 struct DevMesh {
     const float4*   bvh;        // 2 float4 per RtuBvhNode: {bmin.xyz, index} {bmax.xyz, count}
     const float4*   tri;        // 3 float4 per element slot (leaf order)
@@ -45,22 +56,63 @@ struct DevScene {
     float    environment[3];    // environment.SampleEnvironment(...) likewise
 };
 
-// Shade() recursion frames live in an HBM arena, one column per thread:
-// arena[(level * RTU_FRAME_FIELDS + field) * n_threads + thread]
-#define RTU_FRAME_FIELDS 17
+// ---- wavefront state ------------------------------------------------------------
+// MtlBlinn::Shade recurses (depth <= 5, branching <= 3) and combines child results
+// non-linearly. On the GPU the recursion tree is evaluated LEVEL BY LEVEL: every
+// Shade() invocation ("frame") of recursion level L of every pixel lives in level
+// L's frame arrays; all rays of all frames of a level (shadow rays, the refracted /
+// TIR ray, the Fresnel ray, the mirror ray) are traced in parallel by one launch,
+// children become frames of level L+1, and results are combined bottom-up in the
+// reference's exact term order.
+#define RTU_MAX_LEVELS        (RTU_MAX_BOUNCE + 1)
+#define RTU_MAX_SHADOW_LIGHTS 8   // non-ambient lights; more => RTU_ERR_UNSUPPORTED
 
-struct KernelArgs {
-    DevScene   scene;
-    RtuFrameDesc frame;
-    float4*    out;             // shard rows * width
-    float*     arena;
-    unsigned long long* counters;  // 11 x u64 (RtuStats order) or nullptr
-    uint32_t   tiles_x;         // ceil(width / 8)
-    uint32_t   n_threads;       // gridDim.x * 64
+// frame info word (fa.w)
+#define RTU_FI_MTL_MASK   0x3FFFFu        // bits 0-17 material id
+#define RTU_FI_BOUNCE_SH  18              // bits 18-20 bounceCount of this Shade() call
+#define RTU_FI_FRONT      (1u << 21)      // hInfo.front
+#define RTU_FI_SH         (1u << 22)      // light loop runs (front face, mtlFunctions.cpp:125)
+#define RTU_FI_MAIN       (1u << 23)      // refraction property exists and bounce > 0 (:158-160)
+#define RTU_FI_TIR        (1u << 24)      // sinTheta2 > 1 (:205): the main ray is the TIR reflection
+#define RTU_FI_C          (1u << 25)      // reflection property exists and bounce > 0 (:273)
+
+// child status codes in fchild
+#define RTU_CH_NONE   (-1)   // slot not active
+#define RTU_CH_MISS   (-2)   // ray missed
+#define RTU_CH_WHITE  (-3)   // hit a node without material: Shade() == (1,1,1)
+
+struct LevelBuffers {
+    float4* fa;      // {p.xyz, info}
+    float4* fb;      // {N.xyz, level 0: shard-local pixel index}
+    float4* fc;      // {ray dir.xyz, hInfo.z}
+    float4* fres;    // {Shade() result rgb, -}; holds the direct term until combined
+    int4*   fchild;  // {main child, Fresnel child, mirror child, pending}
+    float*  fsh;     // [cap * nsl] Shadow() of every non-ambient light
+    float4* fslot;   // [cap * 3 * 2] closest hit of the three secondary rays: {p.xyz,z} {N.xyz,packed}
+    uint32_t cap;
+    uint32_t pad;
 };
 
-// Launches the variant matching (stack_depth, stats). Returns hipError_t as int.
-int rtu_launch_render(const KernelArgs& args, uint32_t n_blocks, uint32_t bvh_stack_needed, bool stats,
-                      hipStream_t stream);
+struct FrameCounters {
+    uint32_t n_frames[RTU_MAX_LEVELS];
+    uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more
+    uint32_t pad;
+};
+
+struct KernelArgs {
+    DevScene     scene;
+    RtuFrameDesc frame;
+    float4*      out;               // shard rows * width
+    LevelBuffers lv[RTU_MAX_LEVELS];
+    FrameCounters* fcnt;
+    unsigned long long* counters;   // 11 x u64 (RtuStats order) or nullptr
+    uint32_t     tiles_x;           // ceil(width / 8)
+    uint32_t     nsl;               // number of non-ambient lights
+    int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
+};
+
+// Enqueue one frame (primary pass, then per level: trace, consume; then combine
+// bottom-up) on `stream`. Returns hipError_t as int.
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
 
 #endif

@@ -1,0 +1,421 @@
+// rtu_intersect.h — device-side restatement of the reference's ray/scene arithmetic:
+// everything a single ray needs (node transforms, box / sphere / plane / triangle
+// tests, the BVH walk, the scene-graph walk) plus the Snell / Fresnel terms of
+// MtlBlinn::Shade. Shared by every kernel in render_kernel.hip.
+//
+// What replaces what (reference file:line):
+//   to_node / from_node           Node::ToNodeCoords/FromNodeCoords  scene.h:501-512
+//   box_slabs / box_hit           Box::IntersectRay, BVHBoxIntersection  objFunctions.cpp:143-254,408-522
+//   sphere_hit / plane_hit        Sphere/Plane::IntersectRay         objFunctions.cpp:15-140
+//   mesh_hit / tri_hit            TriObj::IntersectRay/IntersectTriangle  objFunctions.cpp:257-406
+//   trace                         Trace / ShadowTrace                RenderFunctions.cpp:181-240
+//   refraction_terms / schlick    MtlBlinn::Shade                    mtlFunctions.cpp:160-203,236-237
+//
+// Bit parity: compiled -ffp-contract=off with IEEE divide/sqrt; every expression
+// keeps the reference's order and its float->double promotions.
+#ifndef RTU_INTERSECT_H_INCLUDED
+#define RTU_INTERSECT_H_INCLUDED
+
+#include "rtu_device.h"
+
+namespace {
+
+struct Ray {
+    f3 p, dir;
+};
+
+struct Hit {  // HitInfo without uvw/duvw (no textures on this path) — scene.h:150-163
+    float z;
+    f3    p, N;
+    int   node;
+    bool  front;
+};
+
+struct Counters {
+    unsigned prim, prim_hit, sec, shd, node, mesh, inner, leafv, leafe, tri, acc;
+};
+
+#define RTU_CNT(field) do { if (STATS) cnt.field++; } while (0)
+
+// ---------------------------------------------------------------------------
+// Node::ToNodeCoords (scene.h:501-507): p' = itm*(p-pos); d' = itm*((p+d)-pos) - p'
+template <class NodeT>
+__device__ __forceinline__ Ray to_node(const NodeT& n, const Ray& r) {
+    f3 pos = ld3(n.pos);
+    Ray o;
+    o.p = mat_mul(n.itm, r.p - pos);
+    o.dir = mat_mul(n.itm, (r.p + r.dir) - pos) - o.p;
+    return o;
+}
+// Node::FromNodeCoords (scene.h:508-512)
+template <class NodeT>
+__device__ __forceinline__ void from_node(const NodeT& n, Hit& h) {
+    h.p = mat_mul(n.tm, h.p) + ld3(n.pos);
+    h.N = norm3(mat_tmul(n.itm, h.N));
+}
+
+// ---------------------------------------------------------------------------
+// Slab interval of Box::IntersectRay / BVHBoxIntersection (objFunctions.cpp:143-254,
+// 408-522). The reference has four branches keyed on the first exactly-zero
+// direction component; each branch evaluates the same per-axis quotients and
+// only differs in which axes enter max/min, so the quotients are computed
+// unconditionally (IEEE: a division by zero cannot trap) and selected.
+__device__ __forceinline__ void box_slabs(const Ray& r, f3 bmin, f3 bmax, float& tEntry, float& tExit) {
+    float tx0 = (bmin.x - r.p.x) / r.dir.x;
+    float tx1 = (bmax.x - r.p.x) / r.dir.x;
+    float ty0 = (bmin.y - r.p.y) / r.dir.y;
+    float ty1 = (bmax.y - r.p.y) / r.dir.y;
+    float tz0 = (bmin.z - r.p.z) / r.dir.z;
+    float tz1 = (bmax.z - r.p.z) / r.dir.z;
+    if (tx0 > tx1) { float t = tx1; tx1 = tx0; tx0 = t; }
+    if (ty0 > ty1) { float t = ty1; ty1 = ty0; ty0 = t; }
+    if (tz0 > tz1) { float t = tz1; tz1 = tz0; tz0 = t; }
+    if (r.dir.x == 0) {
+        tEntry = smax(tz0, ty0);
+        tExit = smin(tz1, ty1);
+    } else if (r.dir.y == 0) {
+        tEntry = smax(tz0, tx0);
+        tExit = smin(tz1, tx1);
+    } else if (r.dir.z == 0) {
+        tEntry = smax(ty0, tx0);
+        tExit = smin(ty1, tx1);
+    } else {
+        tEntry = smax(smax(tx0, ty0), tz0);
+        tExit = smin(smin(tx1, ty1), tz1);
+    }
+}
+__device__ __forceinline__ bool box_empty(f3 bmin, f3 bmax) {  // Box::IsEmpty, scene.h:85
+    return bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z;
+}
+// Box::IntersectRay(r, t_max) (objFunctions.cpp:143-254)
+__device__ __forceinline__ bool box_hit(const Ray& r, f3 bmin, f3 bmax, float t_max) {
+    if (box_empty(bmin, bmax)) return false;
+    float tEntry, tExit;
+    box_slabs(r, bmin, bmax, tEntry, tExit);
+    return tEntry <= tExit && tEntry < t_max;
+}
+
+// ---------------------------------------------------------------------------
+// Sphere::IntersectRay (objFunctions.cpp:15-104), including the stale-z
+// fall-through of the n<m branch. uvw is not produced (no
+// textures on this path).
+__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
+    if (!box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
+    float a = dot3(ray.dir, ray.dir);
+    float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
+    float c = dot3(ray.p, ray.p) - 1;
+    float sqrtCheck = b * b - 4 * a * c;
+    float sq = sqrtf(sqrtCheck);
+    float m = (-b + sq) / (2 * a);
+    float n = (-b - sq) / (2 * a);
+    bool ret = false;
+    if (m == n && m < h.z && (double)m >= 0.001) {
+        h.z = m;
+        h.front = true;
+        ret = true;
+    } else if (m < n && m < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
+        if ((double)m <= 0.001 && (double)n > 0.001 && n < h.z) {
+            h.z = n;
+            h.front = false;
+        } else if ((double)m > 0.001) {
+            h.z = m;
+            h.front = true;
+        }
+        ret = true;
+    } else if (n < m && n < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
+        if ((double)n <= 0.001 && (double)m > 0.001 && m < h.z) {
+            h.z = m;
+            h.front = false;
+        } else if ((double)n > 0.001) {
+            h.z = n;
+            h.front = true;
+        }
+        ret = true;
+    }
+    if (ret) {
+        f3 temp = ray.p + ray.dir * h.z;  // h.z may be stale: reproduced on purpose
+        f3 nn = norm3(temp);
+        h.N = h.front ? nn : -nn;
+        h.p = temp;
+    }
+    return ret;
+}
+
+// Plane::IntersectRay (objFunctions.cpp:107-140)
+__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) {
+    if (!box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
+    if (ray.dir.z != 0) {
+        float t = (-ray.p.z) / (ray.dir.z);
+        if ((double)t > 0.001 && t < h.z) {
+            f3 q = ray.p + ray.dir * t;
+            if (q.x > -1 && q.x < 1 && q.y > -1 && q.y < 1) {
+                h.front = ray.p.z > 0;
+                h.N = mk3(0, 0, h.front ? 1.0f : -1.0f);
+                h.z = t;
+                h.p = mk3(q.x, q.y, 0);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// Point2::Cross (cyPoint.h:247-249)
+__device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return (-ay) * bx + ax * by; }
+
+// cyTriMesh::Interpolate (cyTriMesh.h:191)
+__device__ __forceinline__ f3 interp(const float* arr, const uint32_t* face, f3 bc) {
+    return (ld3(arr + 3 * face[0]) * bc.x + ld3(arr + 3 * face[1]) * bc.y) + ld3(arr + 3 * face[2]) * bc.z;
+}
+
+// TriObj::IntersectTriangle (objFunctions.cpp:257-328) on a pre-gathered triangle
+// record {A,N.x | B,N.y | C,N.z}.
+template <bool STATS>
+__device__ __forceinline__ bool tri_hit(const RTU_CONST DevMesh& mesh, uint32_t slot, const Ray& ray, Hit& h, Counters& cnt) {
+    RTU_CNT(tri);
+    float4 r0 = mesh.tri[3 * slot + 0];
+    float4 r1 = mesh.tri[3 * slot + 1];
+    float4 r2 = mesh.tri[3 * slot + 2];
+    f3 A = mk3(r0.x, r0.y, r0.z), B = mk3(r1.x, r1.y, r1.z), C = mk3(r2.x, r2.y, r2.z);
+    f3 N = mk3(r0.w, r1.w, r2.w);
+    float dn = dot3(ray.dir, N);
+    if (dn != 0) {
+        float t = dot3(A - ray.p, N) / dn;
+        if ((double)t > 0.00001 && t < h.z) {
+            f3 q = ray.p + ray.dir * t;
+            float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
+            float maxNormalAxis = smax(smax(anx, any), anz);
+            float ax, ay, bx, by, cx, cy, qx, qy;
+            if (maxNormalAxis == anx) {
+                ax = A.y; ay = A.z; bx = B.y; by = B.z; cx = C.y; cy = C.z; qx = q.y; qy = q.z;
+            } else if (maxNormalAxis == any) {
+                ax = A.x; ay = A.z; bx = B.x; by = B.z; cx = C.x; cy = C.z; qx = q.x; qy = q.z;
+            } else {
+                ax = A.x; ay = A.y; bx = B.x; by = B.y; cx = C.x; cy = C.y; qx = q.x; qy = q.y;
+            }
+            // "/2.0" is evaluated in fp64 in the reference (:298-300); halving is exact in
+            // binary32 as well except when the result is subnormal, so keep the fp64 form.
+            float TriABCArea = (float)((double)cross2(cx - ax, cy - ay, bx - ax, by - ay) / 2.0);
+            float TriAPCArea = (float)((double)cross2(cx - ax, cy - ay, qx - ax, qy - ay) / 2.0);
+            float TriABPArea = (float)((double)cross2(qx - ax, qy - ay, bx - ax, by - ay) / 2.0);
+            float BC1 = TriAPCArea / TriABCArea;
+            float BC2 = TriABPArea / TriABCArea;
+            float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
+            if (BC1 > 0 && BC2 > 0 && BC3 > 0 && BC1 < 1 && BC2 < 1 && BC3 < 1) {
+                RTU_CNT(acc);
+                f3 bc = mk3(BC3, BC1, BC2);
+                uint32_t face = mesh.elements[slot];
+                h.front = dn < 0;
+                h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, bc));
+                h.z = t;
+                h.p = interp(mesh.v, mesh.f + 3 * face, bc);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// TriObj::IntersectRay (objFunctions.cpp:333-406) — the hot loop on mesh scenes.
+//
+// Same visiting ORDER as the reference (near child first by tEntry+0.01, ties to the
+// first child; leaves tested in element order), restructured for a 64-wide wavefront:
+//  * the reference pushes both children (far first) and pops; popping the near child
+//    right after pushing it equals continuing with it, so only the far child is
+//    pushed, and it is pushed as {index,count} so a pop needs no node fetch: every
+//    inner step is ONE 64-byte fetch (the sibling pair);
+//  * "while-while": all lanes descend through inner nodes together and test
+//    triangles together, instead of mixing both bodies in every iteration.
+// CULL (the fast variant; the counting variant walks exactly the reference's set of
+// nodes so its counters equal the CPU oracle's):
+//  * a shadow ray only asks "is there an occluder" (GenLight::Shadow,
+//    lightFunctions.cpp:27-37: any hit has z > 0) -> leave at the first accepted triangle;
+//  * a child box is skipped when its entry distance is beyond the current h.z by a
+//    margin that covers the rounding of the slab and triangle arithmetic (see
+//    DESIGN.md "Culling margin"): every triangle in it would fail `t < hInfo.z`
+//    (objFunctions.cpp:270), so skipping it cannot change any output bit.
+template <int STACK, bool STATS, bool CULL>
+__device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
+    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
+    RTU_CNT(mesh);
+    // margin of the h.z cull, relative: 1e-3 + 8e-6 / (smallest normalised |dir| component)
+    float cullK = 0.0f;
+    if (CULL) {
+        float ax = fabsf(ray.dir.x), ay = fabsf(ray.dir.y), az = fabsf(ray.dir.z);
+        float mn = fminf(ax, fminf(ay, az));
+        cullK = 1.0f + 1e-3f + 8e-6f * (len3(ray.dir) / mn);  // +inf for an axis-parallel ray: never cull
+    }
+    bool hitResult = false;
+    int sp = 0;
+    float4 r0 = mesh.bvh[2], r1 = mesh.bvh[3];  // root = node 1 (cyBVH.h:76)
+    uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
+    bool alive = true;
+    while (alive) {
+        while (alive && count == 0) {  // inner nodes
+            RTU_CNT(inner);
+            const float4* pair = mesh.bvh + 2 * index;  // children index, index+1: one 64-byte line
+            float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
+            float e1, x1, e2, x2;
+            f3 amin = mk3(a0.x, a0.y, a0.z), amax = mk3(a1.x, a1.y, a1.z);
+            f3 bmin = mk3(b0.x, b0.y, b0.z), bmax = mk3(b1.x, b1.y, b1.z);
+            box_slabs(ray, amin, amax, e1, x1);
+            box_slabs(ray, bmin, bmax, e2, x2);
+            // BVHBoxIntersection (:408-522): -t_max for an empty box, tEntry + 0.01 (fp64) on a hit, else t_max
+            float t1 = box_empty(amin, amax) ? -RTU_BIGFLOAT : ((e1 <= x1 && e1 < RTU_BIGFLOAT) ? (float)((double)e1 + 0.01) : RTU_BIGFLOAT);
+            float t2 = box_empty(bmin, bmax) ? -RTU_BIGFLOAT : ((e2 <= x2 && e2 < RTU_BIGFLOAT) ? (float)((double)e2 + 0.01) : RTU_BIGFLOAT);
+            bool v1 = t1 != RTU_BIGFLOAT, v2 = t2 != RTU_BIGFLOAT;
+            if (CULL) {
+                float lim = h.z * cullK + 1e-4f;
+                v1 = v1 && !(e1 > lim);
+                v2 = v2 && !(e2 > lim);
+            }
+            // :361-389: (t1 <= t2) push c2 then c1; else push c1 then c2
+            bool firstIsC1 = t1 <= t2;
+            uint32_t nearP = firstIsC1 ? (__float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28)) : (__float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28));
+            uint32_t farP = firstIsC1 ? (__float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28)) : (__float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28));
+            bool nearV = firstIsC1 ? v1 : v2, farV = firstIsC1 ? v2 : v1;
+            uint32_t next;
+            if (nearV) {
+                if (farV) {
+                    if (sp < STACK) stk[sp * 64] = farP;
+                    sp++;
+                }
+                next = nearP;
+            } else if (farV) {
+                next = farP;
+            } else if (sp > 0) {
+                sp--;
+                next = stk[sp * 64];
+            } else {
+                alive = false;
+                next = 1u << 28;  // leave the inner loop
+            }
+            index = next & 0x0FFFFFFFu;
+            count = next >> 28;
+        }
+        if (alive) {  // leaf: :394-396
+            RTU_CNT(leafv);
+            if (STATS) cnt.leafe += count;
+            for (uint32_t i = 0; i < count; i++) hitResult |= tri_hit<STATS>(mesh, index + i, ray, h, cnt);
+            if (CULL && shadow && hitResult) {
+                alive = false;
+            } else if (sp > 0) {
+                sp--;
+                uint32_t next = stk[sp * 64];
+                index = next & 0x0FFFFFFFu;
+                count = next >> 28;
+            } else {
+                alive = false;
+            }
+        }
+    }
+    return hitResult;
+}
+
+// ---------------------------------------------------------------------------
+// Trace / ShadowTrace (RenderFunctions.cpp:181-240), recursion over the node tree
+// flattened to a pre-order loop. Only h.z (and h.front in the sphere quirk) feeds
+// later intersection tests, so applying FromNodeCoords for the hit node and all of
+// its ancestors immediately is equivalent to the reference applying them as the
+// recursion unwinds.
+//
+// ONE instantiation serves both kinds of ray: `shadow` is a per-lane flag, so
+// lanes casting shadow rays and lanes casting reflection / refraction rays walk
+// the scene together (better SIMD occupancy, a quarter of the code size of four
+// specialised copies — the kernel has to stay inside the instruction cache).
+template <int STACK, bool STATS, bool CULL>
+__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
+    const RTU_CONST DevNode* nodes = as_const(s.nodes);
+    const RTU_CONST DevMesh* meshes = as_const(s.meshes);
+    bool any = false;
+    Ray r0 = to_node(nodes[0], wr);  // ray inside the root node
+    Ray rp = r0;                     // ray inside node `rp_node` (cached parent space)
+    int rp_node = 0;
+    for (uint32_t k = 0; k < s.n_nodes; k++) {
+        const RTU_CONST DevNode& n = nodes[k];
+        if (n.obj_type == RTU_OBJ_NONE) continue;
+        if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
+        int parent = n.parent;
+        Ray pr;
+        if (parent < 0) {
+            pr = wr;
+        } else {
+            if (parent != rp_node) {
+                const RTU_CONST DevNode& pn = nodes[parent];
+                Ray t = r0;
+                for (int d = 1; d <= pn.depth; d++) t = to_node(nodes[pn.chain[d]], t);
+                rp = t;
+                rp_node = parent;
+            }
+            pr = rp;
+        }
+        Ray lr = to_node(n, pr);
+        RTU_CNT(node);
+        bool hit;
+        if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h);
+        else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h);
+        else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
+        if (hit) {
+            any = true;
+            if (!shadow) {
+                h.node = (int)k;
+                from_node(n, h);
+                for (int j = parent; j >= 0; j = nodes[j].parent) from_node(nodes[j], h);
+            }
+        }
+    }
+    return any;
+}
+
+// sampledNormal of mtlFunctions.cpp:162-165 / :275-277 with SampleSphere(...,0) == (0,0,0)
+__device__ __forceinline__ f3 sampled_normal(f3 p, f3 N) {
+    f3 sampleOrigin = p + N;
+    return norm3((sampleOrigin + mk3(0, 0, 0)) - p);
+}
+__device__ __forceinline__ f3 reflect_dir(f3 dir, f3 sn) {  // :207, :239, :280
+    float k = 2 * dot3(dir, sn);
+    return norm3(dir - sn * k);
+}
+
+// Snell / Fresnel terms of mtlFunctions.cpp:168-203,236-237. Recomputed from the
+// frame whenever a stage resumes (pure ALU) instead of being saved.
+struct Refr {
+    f3    sn;          // sampled normal
+    float cosTheta1;   // after clamping
+    float sinTheta2, cosTheta2;
+    float n1, n2;
+    f3    SVector;
+};
+__device__ __forceinline__ Refr refraction_terms(f3 dir, f3 p, f3 N, bool front, float ior) {
+    Refr r;
+    r.sn = sampled_normal(p, N);
+    float cosTheta1 = dot3(r.sn, -dir);
+    float sinTheta1 = (float)sqrt(1 - (double)cosTheta1 * (double)cosTheta1);  // :169 (pow(x,2) is exact in fp64)
+    if (sinTheta1 > 1) sinTheta1 = 1.0f;
+    if (sinTheta1 < -1) sinTheta1 = -1.0f;
+    if (cosTheta1 > 1) cosTheta1 = 1.0f;
+    if (cosTheta1 < -1) cosTheta1 = -1.0f;
+    r.cosTheta1 = cosTheta1;
+    r.n1 = ior;
+    r.n2 = 1.0f;
+    if (front) { r.n1 = 1.0f; r.n2 = ior; }
+    r.sinTheta2 = (r.n1 / r.n2) * sinTheta1;
+    r.cosTheta2 = sqrtf(1 - r.sinTheta2 * r.sinTheta2);  // :197
+    if (r.cosTheta2 > 1) r.cosTheta2 = 1.0f;
+    r.SVector = norm3(cross3(r.sn, norm3(cross3(r.sn, -dir))));  // :203
+    return r;
+}
+__device__ __forceinline__ float schlick(const Refr& r) {  // :236-237
+    float q = (r.n1 - r.n2) / (r.n1 + r.n2);
+    float R0 = (float)((double)q * (double)q);
+    double x = 1.0 - (double)r.cosTheta1;
+    double x5 = x * x * x * x * x;  // pow(x,5); affects colour only (tolerance +-1/255)
+    return (float)((double)R0 + (1.0 - (double)R0) * x5);
+}
+__device__ __forceinline__ f3 absorb(float z, f3 absorption) {  // :213-215, :259-261
+    return mk3(expf((-z) * absorption.x), expf((-z) * absorption.y), expf((-z) * absorption.z));
+}
+
+}  // namespace
+
+#endif

@@ -17,7 +17,7 @@ struct f3 {
 };
 
 RTU_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-RTU_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+template <class P> RTU_HD f3 ld3(P p) { return mk3(p[0], p[1], p[2]); }  // any address space
 RTU_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RTU_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RTU_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
@@ -34,13 +34,13 @@ RTU_HD f3 norm3(f3 a) { return a / len3(a); }              // cyPoint.h:295: thr
 RTU_HD bool not_black(f3 c) { return c.x != 0 || c.y != 0 || c.z != 0; }  // Color::operator!=, cyColor.h:115
 
 // Matrix3 * Point3, column-major (cyMatrix.h:543-547)
-RTU_HD f3 mat_mul(const float* m, f3 p) {
+template <class P> RTU_HD f3 mat_mul(P m, f3 p) {
     return mk3((p.x * m[0] + p.y * m[3]) + p.z * m[6],
                (p.x * m[1] + p.y * m[4]) + p.z * m[7],
                (p.x * m[2] + p.y * m[5]) + p.z * m[8]);
 }
 // Transformation::TransposeMult (scene.h:253-260)
-RTU_HD f3 mat_tmul(const float* m, f3 d) {
+template <class P> RTU_HD f3 mat_tmul(P m, f3 d) {
     return mk3(dot3(mk3(m[0], m[1], m[2]), d), dot3(mk3(m[3], m[4], m[5]), d), dot3(mk3(m[6], m[7], m[8]), d));
 }
 

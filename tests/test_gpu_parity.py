@@ -54,7 +54,9 @@ def test_gpu_vs_oracle_and_golden(pkg, orc, ctx, golden, tag):
     g = golden(tag)
     scene = g.scene(pkg)
     W, H = g.width, g.height
-    gpu, gstats = render_gpu(pkg, ctx, scene, W, H)
+    gpu, gstats = render_gpu(pkg, ctx, scene, W, H)          # counting variant: walks the reference's node set
+    fast, _ = render_gpu(pkg, ctx, scene, W, H, stats=False)  # fast variant: culling, any-hit shadows, speculative Fresnel ray
+    assert np.array_equal(gpu.view(np.uint32), fast.view(np.uint32)), "fast and counting variants differ"
     cpu, cstats = orc.render(scene, W, H, threads=8)
     nflip = check_against(gpu, cpu, orc)
     assert gstats == cstats, "counters differ"

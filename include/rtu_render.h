@@ -120,6 +120,13 @@ int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
 int  rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream,
                      int iters, float* avg_ms_out);
 
+/* Self-test: the kernels replace binary32 divisions by a per-ray constant with an exact
+ * binary64-reciprocal form (rtu_intersect.h); this runs n_pairs pseudo-random operand
+ * pairs through both forms on the GPU and returns how many quotients differ in any bit
+ * (must be 0). */
+int  rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned long long seed,
+                           unsigned long long* mismatches_out);
+
 /* Device memory helpers so a C/C++ host needs no HIP headers. */
 void* rtu_device_alloc(RtuContext* ctx, size_t bytes);
 void  rtu_device_free(RtuContext* ctx, void* d_ptr);

@@ -60,6 +60,24 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
     return base + (uint32_t)__popcll(below);
 }
 
+// Largest shard population of level L (wave-uniform): lane i reads shard i's counter.
+__device__ __forceinline__ uint32_t level_max_count(const KernelArgs& a, int L) {
+    uint32_t v = a.fcnt->n_frames[L][lane_id() % RTU_SHARDS];
+    const uint32_t cap = a.lv[L].cap_s;
+    if (v > cap) v = cap;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t shard_count(const KernelArgs& a, int L, uint32_t shard) {
+    uint32_t v = a.fcnt->n_frames[L][shard];
+    const uint32_t cap = a.lv[L].cap_s;
+    return v > cap ? cap : v;
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counters& cnt) {
     if (!STATS) return;
@@ -104,11 +122,13 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
 
 // ------------------------------------------------------------------------------------
 template <int STACK, bool STATS>
-__global__ void __launch_bounds__(64) k_primary(KernelArgs a) {
-    __shared__ uint32_t s_stack[STACK * 64];
+__global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
+    __shared__ uint32_t s_stack_all[4 * STACK * 64];
+    uint32_t* s_stack = s_stack_all + (threadIdx.x >> 6) * (STACK * 64);
     const DevScene& s = a.scene;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;  // whole wavefront
     const uint32_t band_local = tile / a.tiles_x;
     const uint32_t tx = tile - band_local * a.tiles_x;
     const int x = (int)(tx * 8 + (lane & 7));
@@ -140,10 +160,12 @@ __global__ void __launch_bounds__(64) k_primary(KernelArgs a) {
             else want = true;
         }
     }
-    uint32_t idx = wave_append(&a.fcnt->n_frames[0], want);
+    const uint32_t shard = tile % RTU_SHARDS;
+    uint32_t idx = wave_append(&a.fcnt->n_frames[0][shard], want);
     if (want) {
         const LevelBuffers& lv = a.lv[0];
-        if (idx < lv.cap) {
+        if (idx < lv.cap_s) {
+            idx += shard * lv.cap_s;
             uint32_t info = make_info(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N);
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
@@ -163,16 +185,18 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
-    uint32_t n = a.fcnt->n_frames[L];
-    if (n > lv.cap) n = lv.cap;
-    const uint32_t chunks = (n + 63u) / 64u;
+    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;  // 64-frame chunks per shard
+    const uint32_t chunks = kmax * RTU_SHARDS;                  // per slot
     const uint32_t nslots = a.nsl + 3u;
     const uint32_t total = chunks * nslots;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
         const uint32_t slot = c / chunks;
-        const uint32_t f = (c - slot * chunks) * 64u + lane;
-        if (f >= n) continue;
+        const uint32_t cc = c - slot * chunks;
+        const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
+        const uint32_t fl = k * 64u + lane;
+        if (fl >= shard_count(a, L, shard)) continue;
+        const uint32_t f = shard * lv.cap_s + fl;
         const float4 fa = lv.fa[f];
         const uint32_t info = __float_as_uint(fa.w);
         const f3 p = mk3(fa.x, fa.y, fa.z);
@@ -271,13 +295,14 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
     const int Ln = haveNext ? L + 1 : L;
     const LevelBuffers& nx = a.lv[Ln];
     const uint32_t lane = threadIdx.x;
-    uint32_t n = a.fcnt->n_frames[L];
-    if (n > lv.cap) n = lv.cap;
     const f3 cam_pos = ld3(a.frame.cam_pos);
-    const uint32_t chunks = (n + 63u) / 64u;
+    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
+    const uint32_t chunks = kmax * RTU_SHARDS;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t f = c * 64u + lane;
-        const bool active = f < n;
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        const uint32_t fl = k * 64u + lane;
+        const bool active = fl < shard_count(a, L, shard);
+        const uint32_t f = shard * lv.cap_s + fl;
         float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
         if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
         const uint32_t info = __float_as_uint(fa.w);
@@ -344,11 +369,13 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
             const int cmid = (int)(packed >> 2) - 1;
             const bool spawn = hit && cmid >= 0 && haveNext;
             if (k == SLOT_MAIN && hit) { bz = s0.w; bfront = (packed & 2u) != 0; }
-            const uint32_t idx = wave_append(&a.fcnt->n_frames[Ln], spawn);  // all 64 lanes take part
+            const uint32_t cshard = c % RTU_SHARDS;
+            uint32_t idx = wave_append(&a.fcnt->n_frames[Ln][cshard], spawn);  // all 64 lanes take part
             if (!slotActive) continue;
             if (!hit) st[k] = RTU_CH_MISS;
             else if (cmid < 0) st[k] = RTU_CH_WHITE;
-            else if (spawn && idx < nx.cap) {
+            else if (spawn && idx < nx.cap_s) {
+                idx += cshard * nx.cap_s;
                 // the child Shade(): ray direction, hit point and normal of the secondary ray
                 const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
                 const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
@@ -381,12 +408,13 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
-    uint32_t n = a.fcnt->n_frames[L];
-    if (n > lv.cap) n = lv.cap;
-    const uint32_t chunks = (n + 63u) / 64u;
+    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
+    const uint32_t chunks = kmax * RTU_SHARDS;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t f = c * 64u + threadIdx.x;
-        if (f >= n) continue;
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        const uint32_t fl = k * 64u + threadIdx.x;
+        if (fl >= shard_count(a, L, shard)) continue;
+        const uint32_t f = shard * lv.cap_s + fl;
         const float4 fa = lv.fa[f];
         const uint32_t info = __float_as_uint(fa.w);
         if (!(info & (RTU_FI_MAIN | RTU_FI_C))) continue;  // never had secondary rays
@@ -418,14 +446,38 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     }
 }
 
+// Self-test of the exact-division identity used by the slab and barycentric tests
+// (rtu_intersect.h, fdiv): pseudo-random bit patterns (all exponents, subnormals, zeros,
+// infinities, NaNs) plus same-exponent pairs; counts quotients whose bits differ from `/`.
+__global__ void k_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n_pairs;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + seed) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        unsigned int nb = (unsigned int)x, db = (unsigned int)(x >> 32);
+        unsigned int mode = (unsigned int)(i & 7u);
+        if (mode == 1) db = (db & 0x007FFFFFu) | (nb & 0xFF800000u);          // same exponent: quotient near 1
+        if (mode == 2) nb = (nb & 0x807FFFFFu) | 0x3F800000u;                   // n in [1,2)
+        if (mode == 3) { nb &= 0x80FFFFFFu; db = (db & 0x80FFFFFFu) | 0x7E000000u; }  // tiny / huge -> subnormal quotients
+        if (mode == 4) db &= 0x807FFFFFu;                                       // subnormal / zero divisor
+        float n = __uint_as_float(nb), d = __uint_as_float(db);
+        float q1 = n / d;
+        float q2 = fdiv(n, 1.0 / (double)d);
+        bool same = __float_as_uint(q1) == __float_as_uint(q2) || (q1 != q1 && q2 != q2);
+        if (!same) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 template <int STACK>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
     const dim3 gridT(16384), gridF(4096);  // persistent grids: 64-frame chunks are strided over them
     if (n_tiles == 0) return (int)hipSuccess;
-    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3(n_tiles), block, 0, stream, a);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3(n_tiles), block, 0, stream, a);
+    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, a, n_tiles);
+    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, a, n_tiles);
     for (int L = 0; L < levels; L++) {
         if (stats) {
             hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C));
@@ -441,6 +493,11 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
 }
 
 }  // namespace
+
+int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selftest_fdiv, dim3(4096), dim3(256), 0, stream, n_pairs, seed, d_mismatches);
+    return (int)hipGetLastError();
+}
 
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
     if (bvh_stack_needed <= 16) return launch_all<16>(args, n_tiles, stats, stream);

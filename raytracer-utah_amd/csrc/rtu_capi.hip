@@ -185,12 +185,16 @@ int alloc_level(RtuContext* ctx, T** dst, size_t count) {
 // Frame arrays of every recursion level (rtu_device.h). Level 0 holds at most one
 // frame per pixel; deeper levels get cap_scale * pixels and are grown on overflow.
 int ensure_levels(RtuContext* ctx, uint32_t pixels) {
-    if (ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && ctx->lv[1].cap >= ctx->cap_scale * pixels) return RTU_OK;
+    // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile
+    size_t tiles = ((size_t)pixels + 63) / 64 + 8;  // +8: ragged right/bottom tiles
+    size_t cap_s0 = ((tiles + RTU_SHARDS - 1) / RTU_SHARDS) * 64;
+    if (ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && ctx->lv[1].cap_s >= ctx->cap_scale * cap_s0) return RTU_OK;
     free_levels(ctx);
     int rc;
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         LevelBuffers& lv = ctx->lv[L];
-        size_t cap = L == 0 ? pixels : (size_t)pixels * ctx->cap_scale;
+        size_t cap_s = L == 0 ? cap_s0 : cap_s0 * ctx->cap_scale;
+        size_t cap = cap_s * RTU_SHARDS;
         if (cap > 0x7FFFFFF0u) return fail(ctx, RTU_ERR_UNSUPPORTED, "frame capacity overflow");
         if ((rc = alloc_level(ctx, &lv.fa, cap)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fb, cap)) != RTU_OK) return rc;
@@ -199,7 +203,7 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
         if ((rc = alloc_level(ctx, &lv.fchild, cap)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
-        lv.cap = (uint32_t)cap;
+        lv.cap_s = (uint32_t)cap_s;
     }
     ctx->level_cap0 = pixels;
     ctx->level_nsl = ctx->nsl;
@@ -341,15 +345,35 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         const RtuMesh& m = s->meshes[mi];
         DevMesh& d = meshes[mi];
         memset(&d, 0, sizeof d);
-        // triangle records in leaf order: {A,N.x | B,N.y | C,N.z}; N as objFunctions.cpp:263
-        std::vector<float4> tri((size_t)m.n_elements * 3);
+        // triangle records in leaf order (TriRec, rtu_intersect.h): the ray-independent part of
+        // TriObj::IntersectTriangle (objFunctions.cpp:259-300) evaluated with the same float ops
+        std::vector<float4> tri((size_t)m.n_elements * 4);
         for (uint32_t e = 0; e < m.n_elements; e++) {
             const uint32_t* fv = m.f + 3 * m.elements[e];
             f3 A = ld3(m.v + 3 * fv[0]), B = ld3(m.v + 3 * fv[1]), C = ld3(m.v + 3 * fv[2]);
-            f3 N = norm3(cross3(B - A, C - A));
-            tri[3 * e + 0] = make_float4(A.x, A.y, A.z, N.x);
-            tri[3 * e + 1] = make_float4(B.x, B.y, B.z, N.y);
-            tri[3 * e + 2] = make_float4(C.x, C.y, C.z, N.z);
+            f3 N = norm3(cross3(B - A, C - A));                                        // :263
+            float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
+            float maxNormalAxis = smax(smax(anx, any), anz);                           // :274
+            uint32_t axis = (maxNormalAxis == anx) ? 0u : (maxNormalAxis == any) ? 1u : 2u;  // :278-296
+            float ax = axis == 0 ? A.y : A.x, ay = axis == 2 ? A.y : A.z;
+            float bx = axis == 0 ? B.y : B.x, by = axis == 2 ? B.y : B.z;
+            float cx = axis == 0 ? C.y : C.x, cy = axis == 2 ? C.y : C.z;
+            float e1x = cx - ax, e1y = cy - ay, e2x = bx - ax, e2y = by - ay;
+            float TriABCArea = (float)((double)((-e1y) * e2x + e1x * e2y) / 2.0);      // :298, Point2::Cross
+            double rcp = 1.0 / (double)TriABCArea;
+            uint64_t bits;
+            memcpy(&bits, &rcp, 8);
+            uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            float flo, fhi, faxis;
+            memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4); memcpy(&faxis, &axis, 4);
+            tri[4 * e + 0] = make_float4(A.x, A.y, A.z, N.x);
+            tri[4 * e + 1] = make_float4(N.y, N.z, ax, ay);
+            tri[4 * e + 2] = make_float4(e1x, e1y, e2x, e2y);
+            tri[4 * e + 3] = make_float4(flo, fhi, faxis, 0.0f);
+        }
+        for (uint32_t i = 1; i < m.n_bvh_nodes; i++) {
+            const RtuBvhNode& bn = m.bvh[i];
+            if (bn.bmin[0] > bn.bmax[0] || bn.bmin[1] > bn.bmax[1] || bn.bmin[2] > bn.bmax[2]) d.any_empty_box = 1;
         }
         static_assert(sizeof(RtuBvhNode) == 2 * sizeof(float4), "BVH node is two float4");
         if ((rc = upload(ctx, reinterpret_cast<const float4*>(m.bvh), (size_t)m.n_bvh_nodes * 2, &d.bvh)) != RTU_OK) return rc;
@@ -520,6 +544,17 @@ int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, vo
     float ms = 0;
     RTU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms_out = ms / (float)iters;
+    return RTU_OK;
+}
+
+int rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches_out) {
+    if (!ctx || !mismatches_out) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    hipError_t e = (hipError_t)rtu_launch_selftest_fdiv(n_pairs, seed, ctx->counters, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "selftest launch: %s", hipGetErrorString(e));
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RTU_HIP(ctx, hipMemcpy(mismatches_out, ctx->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RTU_OK;
 }
 

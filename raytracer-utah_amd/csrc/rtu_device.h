@@ -5,11 +5,11 @@
 //    scalar cache (s_load), one struct per item, as on the host (rtu_scene.h);
 //  * BVH nodes: 32 B, sibling pairs 64-B aligned -> an inner visit is one
 //    64-byte line (4 x dwordx4);
-//  * triangles: gathered ONCE at upload into leaf order, 48 B per triangle
-//    {A.xyz,N.x | B.xyz,N.y | C.xyz,N.z} so a triangle test is three aligned
-//    16-byte loads and no index chasing; N is the normalised face normal the
-//    reference recomputes per test (objFunctions.cpp:263), evaluated here once
-//    with the same operations;
+//  * triangles: gathered ONCE at upload into leaf order, 64 B per triangle: the vertex
+//    A, the normalised face normal the reference recomputes per test
+//    (objFunctions.cpp:263), the 2-D projected edges and 1/TriABCArea — everything
+//    of IntersectTriangle that does not depend on the ray, evaluated once with the
+//    reference's own float operations; a test is four aligned 16-byte loads;
 //  * per-vertex normals / texcoords stay indexed (touched only on an accepted hit).
 #ifndef RTU_DEVICE_H_INCLUDED
 #define RTU_DEVICE_H_INCLUDED
@@ -30,7 +30,7 @@ template <class T> __device__ __forceinline__ const RTU_CONST T* as_const(const 
 
 struct DevMesh {
     const float4*   bvh;        // 2 float4 per RtuBvhNode: {bmin.xyz, index} {bmax.xyz, count}
-    const float4*   tri;        // 3 float4 per element slot (leaf order)
+    const float4*   tri;        // 4 float4 per element slot (leaf order), see TriRec in rtu_intersect.h
     const uint32_t* elements;   // element slot -> face id
     const uint32_t* f;          // face -> 3 vertex ids
     const float*    v;
@@ -38,6 +38,8 @@ struct DevMesh {
     const float*    vn;
     float    bmin[3], bmax[3];
     uint32_t n_bvh_nodes, n_elements;
+    uint32_t any_empty_box;     // some BVH box has min > max (cannot come from triangles)
+    uint32_t pad;
 };
 
 struct DevNode {                // one scene-graph node (wave-uniform data)
@@ -89,14 +91,20 @@ struct LevelBuffers {
     int4*   fchild;  // {main child, Fresnel child, mirror child, pending}
     float*  fsh;     // [cap * nsl] Shadow() of every non-ambient light
     float4* fslot;   // [cap * 3 * 2] closest hit of the three secondary rays: {p.xyz,z} {N.xyz,packed}
-    uint32_t cap;
+    uint32_t cap_s;  // capacity of ONE shard; frame id = shard * cap_s + index within the shard
     uint32_t pad;
 };
 
+// Frames are appended with one atomic per wavefront. A single counter word saturates at
+// ~88 atomics/us on MI355X (32 400 tiles => ~370 us, measured), so every level's arrays
+// are split into RTU_SHARDS independent regions, each with its own counter; a wavefront
+// appends to the shard of its own index, which keeps the regions balanced.
+#define RTU_SHARDS 64
+
 struct FrameCounters {
-    uint32_t n_frames[RTU_MAX_LEVELS];
+    uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS];
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more
-    uint32_t pad;
+    uint32_t pad[3];
 };
 
 struct KernelArgs {
@@ -114,5 +122,7 @@ struct KernelArgs {
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine
 // bottom-up) on `stream`. Returns hipError_t as int.
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
+
+int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 
 #endif

@@ -84,6 +84,43 @@ __device__ __forceinline__ void box_slabs(const Ray& r, f3 bmin, f3 bmax, float&
         tExit = smin(smin(tx1, ty1), tz1);
     }
 }
+// ---- exact division by a per-ray constant ------------------------------------------
+// The slab test divides by the same three direction components at every BVH node.
+// IEEE binary32 division is ~10 VALU instructions on CDNA4; instead the reciprocal is
+// taken ONCE per ray in binary64 and each quotient is
+//        q = (float)((double)n * rd),   rd = 1.0 / (double)d
+// which is bit-identical to the binary32 quotient n / d for EVERY input:
+//  * rd and the product carry a relative error <= 2^-52 in total;
+//  * the exact quotient of two binary32 numbers is either representable or at least
+//    2^-49 (relative) away from every rounding boundary of binary32 (a midpoint m has
+//    a 25-bit significand M; n - d*m = (N*2^s - D*M) * 2^k is a non-zero integer multiple
+//    of 2^k while |d*m| < 2^(k+49)), so the binary64 value rounds to the same float;
+//  * zeros, infinities and NaN propagate identically (1/±0 = ±inf, 0*inf = NaN, ...).
+// tests/test_gpu_parity.py::test_exact_division checks it against `/` on the GPU.
+struct RayRcp {
+    double rx, ry, rz;
+};
+__device__ __forceinline__ float fdiv(float n, double rd) { return (float)((double)n * rd); }
+__device__ __forceinline__ RayRcp ray_rcp(const Ray& r) {
+    RayRcp c;
+    c.rx = 1.0 / (double)r.dir.x;
+    c.ry = 1.0 / (double)r.dir.y;
+    c.rz = 1.0 / (double)r.dir.z;
+    return c;
+}
+// General case of the slab test (no exactly-zero direction component), objFunctions.cpp:223-245.
+__device__ __forceinline__ void box_slabs_rcp(const Ray& r, const RayRcp& c, f3 bmin, f3 bmax, float& tEntry, float& tExit) {
+    float tx0 = fdiv(bmin.x - r.p.x, c.rx), tx1 = fdiv(bmax.x - r.p.x, c.rx);
+    float ty0 = fdiv(bmin.y - r.p.y, c.ry), ty1 = fdiv(bmax.y - r.p.y, c.ry);
+    float tz0 = fdiv(bmin.z - r.p.z, c.rz), tz1 = fdiv(bmax.z - r.p.z, c.rz);
+    bool sx = tx0 > tx1, sy = ty0 > ty1, sz = tz0 > tz1;
+    float ax0 = sx ? tx1 : tx0, ax1 = sx ? tx0 : tx1;
+    float ay0 = sy ? ty1 : ty0, ay1 = sy ? ty0 : ty1;
+    float az0 = sz ? tz1 : tz0, az1 = sz ? tz0 : tz1;
+    tEntry = smax(smax(ax0, ay0), az0);
+    tExit = smin(smin(ax1, ay1), az1);
+}
+
 __device__ __forceinline__ bool box_empty(f3 bmin, f3 bmax) {  // Box::IsEmpty, scene.h:85
     return bmin.x > bmax.x || bmin.y > bmax.y || bmin.z > bmax.z;
 }
@@ -168,43 +205,48 @@ __device__ __forceinline__ f3 interp(const float* arr, const uint32_t* face, f3 
     return (ld3(arr + 3 * face[0]) * bc.x + ld3(arr + 3 * face[1]) * bc.y) + ld3(arr + 3 * face[2]) * bc.z;
 }
 
-// TriObj::IntersectTriangle (objFunctions.cpp:257-328) on a pre-gathered triangle
-// record {A,N.x | B,N.y | C,N.z}.
+// TriObj::IntersectTriangle (objFunctions.cpp:257-328) on a 64-byte triangle record that
+// holds everything of the test that does not depend on the ray (computed once at
+// upload with the reference's own float operations, rtu_capi.hip):
+//   r0 = {A.xyz, N.x}  r1 = {N.y, N.z, A2.x, A2.y}  r2 = {C2-A2, B2-A2}  r3 = {1/TriABCArea (fp64), axis, -}
+// N = normalised face normal (:263); axis = dominant axis of N (:276-296); *2 = vertex
+// projected on the other two axes; TriABCArea as :298. "/2.0" in fp64 (:298-300) equals
+// "* 0.5f": both are the correctly rounded half. BC1/BC2 divide by the per-triangle
+// constant TriABCArea -> exact reciprocal form (see fdiv).
+struct TriRec {
+    float4 r0, r1, r2, r3;
+};
+__device__ __forceinline__ TriRec load_tri(const RTU_CONST DevMesh& mesh, uint32_t slot) {
+    TriRec t;
+    const float4* p = mesh.tri + 4 * (size_t)slot;
+    t.r0 = p[0]; t.r1 = p[1]; t.r2 = p[2]; t.r3 = p[3];
+    return t;
+}
 template <bool STATS>
-__device__ __forceinline__ bool tri_hit(const RTU_CONST DevMesh& mesh, uint32_t slot, const Ray& ray, Hit& h, Counters& cnt) {
+__device__ __forceinline__ bool tri_hit(const RTU_CONST DevMesh& mesh, uint32_t slot, const TriRec& T, const Ray& ray, Hit& h, Counters& cnt) {
     RTU_CNT(tri);
-    float4 r0 = mesh.tri[3 * slot + 0];
-    float4 r1 = mesh.tri[3 * slot + 1];
-    float4 r2 = mesh.tri[3 * slot + 2];
-    f3 A = mk3(r0.x, r0.y, r0.z), B = mk3(r1.x, r1.y, r1.z), C = mk3(r2.x, r2.y, r2.z);
-    f3 N = mk3(r0.w, r1.w, r2.w);
-    float dn = dot3(ray.dir, N);
+    const f3 A = mk3(T.r0.x, T.r0.y, T.r0.z);
+    const f3 N = mk3(T.r0.w, T.r1.x, T.r1.y);
+    const float dn = dot3(ray.dir, N);
     if (dn != 0) {
-        float t = dot3(A - ray.p, N) / dn;
-        if ((double)t > 0.00001 && t < h.z) {
-            f3 q = ray.p + ray.dir * t;
-            float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
-            float maxNormalAxis = smax(smax(anx, any), anz);
-            float ax, ay, bx, by, cx, cy, qx, qy;
-            if (maxNormalAxis == anx) {
-                ax = A.y; ay = A.z; bx = B.y; by = B.z; cx = C.y; cy = C.z; qx = q.y; qy = q.z;
-            } else if (maxNormalAxis == any) {
-                ax = A.x; ay = A.z; bx = B.x; by = B.z; cx = C.x; cy = C.z; qx = q.x; qy = q.z;
-            } else {
-                ax = A.x; ay = A.y; bx = B.x; by = B.y; cx = C.x; cy = C.y; qx = q.x; qy = q.y;
-            }
-            // "/2.0" is evaluated in fp64 in the reference (:298-300); halving is exact in
-            // binary32 as well except when the result is subnormal, so keep the fp64 form.
-            float TriABCArea = (float)((double)cross2(cx - ax, cy - ay, bx - ax, by - ay) / 2.0);
-            float TriAPCArea = (float)((double)cross2(cx - ax, cy - ay, qx - ax, qy - ay) / 2.0);
-            float TriABPArea = (float)((double)cross2(qx - ax, qy - ay, bx - ax, by - ay) / 2.0);
-            float BC1 = TriAPCArea / TriABCArea;
-            float BC2 = TriABPArea / TriABCArea;
-            float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
+        const float t = dot3(A - ray.p, N) / dn;
+        if ((double)t > 0.00001 && t < h.z) {  // :270
+            const f3 q = ray.p + ray.dir * t;
+            const uint32_t axis = __float_as_uint(T.r3.z);
+            const float qx = axis == 0 ? q.y : q.x;
+            const float qy = axis == 2 ? q.y : q.z;
+            const float ax = T.r1.z, ay = T.r1.w;
+            const float e1x = T.r2.x, e1y = T.r2.y, e2x = T.r2.z, e2y = T.r2.w;  // C2-A2, B2-A2
+            const float TriAPCArea = cross2(e1x, e1y, qx - ax, qy - ay) * 0.5f;
+            const float TriABPArea = cross2(qx - ax, qy - ay, e2x, e2y) * 0.5f;
+            const double rcpABC = __hiloint2double(__float_as_int(T.r3.y), __float_as_int(T.r3.x));
+            const float BC1 = fdiv(TriAPCArea, rcpABC);
+            const float BC2 = fdiv(TriABPArea, rcpABC);
+            const float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
             if (BC1 > 0 && BC2 > 0 && BC3 > 0 && BC1 < 1 && BC2 < 1 && BC3 < 1) {
                 RTU_CNT(acc);
-                f3 bc = mk3(BC3, BC1, BC2);
-                uint32_t face = mesh.elements[slot];
+                const f3 bc = mk3(BC3, BC1, BC2);
+                const uint32_t face = mesh.elements[slot];
                 h.front = dn < 0;
                 h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, bc));
                 h.z = t;
@@ -238,6 +280,13 @@ template <int STACK, bool STATS, bool CULL>
 __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
     if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
     RTU_CNT(mesh);
+    // The reference's slab test has special cases for an exactly-zero direction component
+    // (objFunctions.cpp:154-216). If ANY lane of the wavefront has one, the whole wavefront
+    // takes the literal four-branch form; otherwise the branch-free reciprocal form.
+    const bool zeroDir = ray.dir.x == 0 || ray.dir.y == 0 || ray.dir.z == 0;
+    const bool slowSlabs = __any(zeroDir) != 0;
+    const RayRcp rc = ray_rcp(ray);
+    const bool emptyBoxes = mesh.any_empty_box != 0;  // never for a BVH built from triangles; uniform
     // margin of the h.z cull, relative: 1e-3 + 8e-6 / (smallest normalised |dir| component)
     float cullK = 0.0f;
     if (CULL) {
@@ -258,11 +307,20 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             float e1, x1, e2, x2;
             f3 amin = mk3(a0.x, a0.y, a0.z), amax = mk3(a1.x, a1.y, a1.z);
             f3 bmin = mk3(b0.x, b0.y, b0.z), bmax = mk3(b1.x, b1.y, b1.z);
-            box_slabs(ray, amin, amax, e1, x1);
-            box_slabs(ray, bmin, bmax, e2, x2);
+            if (slowSlabs) {
+                box_slabs(ray, amin, amax, e1, x1);
+                box_slabs(ray, bmin, bmax, e2, x2);
+            } else {
+                box_slabs_rcp(ray, rc, amin, amax, e1, x1);
+                box_slabs_rcp(ray, rc, bmin, bmax, e2, x2);
+            }
             // BVHBoxIntersection (:408-522): -t_max for an empty box, tEntry + 0.01 (fp64) on a hit, else t_max
-            float t1 = box_empty(amin, amax) ? -RTU_BIGFLOAT : ((e1 <= x1 && e1 < RTU_BIGFLOAT) ? (float)((double)e1 + 0.01) : RTU_BIGFLOAT);
-            float t2 = box_empty(bmin, bmax) ? -RTU_BIGFLOAT : ((e2 <= x2 && e2 < RTU_BIGFLOAT) ? (float)((double)e2 + 0.01) : RTU_BIGFLOAT);
+            float t1 = (e1 <= x1 && e1 < RTU_BIGFLOAT) ? (float)((double)e1 + 0.01) : RTU_BIGFLOAT;
+            float t2 = (e2 <= x2 && e2 < RTU_BIGFLOAT) ? (float)((double)e2 + 0.01) : RTU_BIGFLOAT;
+            if (emptyBoxes) {
+                if (box_empty(amin, amax)) t1 = -RTU_BIGFLOAT;
+                if (box_empty(bmin, bmax)) t2 = -RTU_BIGFLOAT;
+            }
             bool v1 = t1 != RTU_BIGFLOAT, v2 = t2 != RTU_BIGFLOAT;
             if (CULL) {
                 float lim = h.z * cullK + 1e-4f;
@@ -271,8 +329,9 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             }
             // :361-389: (t1 <= t2) push c2 then c1; else push c1 then c2
             bool firstIsC1 = t1 <= t2;
-            uint32_t nearP = firstIsC1 ? (__float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28)) : (__float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28));
-            uint32_t farP = firstIsC1 ? (__float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28)) : (__float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28));
+            uint32_t p1 = __float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28);
+            uint32_t p2 = __float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28);
+            uint32_t nearP = firstIsC1 ? p1 : p2, farP = firstIsC1 ? p2 : p1;
             bool nearV = firstIsC1 ? v1 : v2, farV = firstIsC1 ? v2 : v1;
             uint32_t next;
             if (nearV) {
@@ -293,10 +352,16 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             index = next & 0x0FFFFFFFu;
             count = next >> 28;
         }
-        if (alive) {  // leaf: :394-396
+        if (alive) {  // leaf: :394-396; the next record is fetched while the current one is tested
             RTU_CNT(leafv);
             if (STATS) cnt.leafe += count;
-            for (uint32_t i = 0; i < count; i++) hitResult |= tri_hit<STATS>(mesh, index + i, ray, h, cnt);
+            TriRec cur = load_tri(mesh, index);
+            for (uint32_t i = 0; i < count; i++) {
+                TriRec nxt = cur;
+                if (i + 1 < count) nxt = load_tri(mesh, index + i + 1);
+                hitResult |= tri_hit<STATS>(mesh, index + i, cur, ray, h, cnt);
+                cur = nxt;
+            }
             if (CULL && shadow && hitResult) {
                 alive = false;
             } else if (sp > 0) {

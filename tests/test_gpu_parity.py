@@ -157,6 +157,15 @@ def test_begin_render_dropin(pkg, orc, golden, tmp_path):
     assert np.abs(rgb.astype(np.int32) - g.npz["result_u8"].astype(np.int32)).max() <= RGB8_TOL
 
 
+def test_exact_division(pkg, ctx):
+    """(float)((double)n * (1.0/(double)d)) == n / d bit for bit (rtu_intersect.h fdiv): 2^31
+    pseudo-random operand pairs incl. subnormals, zeros, infinities, NaNs, near-1 quotients."""
+    bad = ctypes.c_ulonglong(123)
+    for seed in (0, 0x1234567):
+        assert pkg.hip.rtu_selftest_division(ctx._h, 1 << 30, seed, ctypes.byref(bad)) == 0
+        assert bad.value == 0, "%d quotients differ" % bad.value
+
+
 def test_errors_are_codes_not_crashes(pkg, ctx, golden):
     g = golden("p1_256")
     scene = g.scene(pkg)

@@ -121,21 +121,55 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
 }
 
 // ------------------------------------------------------------------------------------
-template <int STACK, bool STATS>
-__global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
-    __shared__ uint32_t s_stack_all[4 * STACK * 64];
-    uint32_t* s_stack = s_stack_all + (threadIdx.x >> 6) * (STACK * 64);
+// TWO-STAGE PHASES. A ray that never enters a mesh's bounding box costs a few hundred
+// instructions; one that does walks a BVH (tens to hundreds of dependent steps) and a
+// wavefront is as slow as its slowest lane. So every tracing phase runs twice:
+//   stage 1 (wide): 64 rays per wavefront; the scene-graph walk is abandoned the moment a
+//           ray passes a mesh's bounding box and the ray id is appended to a defer list;
+//   stage 2 (narrow): the deferred rays, compacted, walk the whole scene including the
+//           BVH with only R rays per wavefront (R = 8..64 chosen from the list length), so
+//           a wavefront waits for the slowest of R rays instead of 64 and all of its lanes
+//           are inside the BVH loop together.
+// The counting variant (STATS) does everything in stage 1 so that every node test is
+// counted exactly once.
+
+// Append one ray id to the defer list of phase `ph` (sharded like the frame arrays).
+__device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t shard, bool want, uint32_t id) {
+    uint32_t idx = wave_append(&a.fcnt->n_defer[ph][shard], want);
+    if (want) {
+        if (idx < a.defer_cap_s) a.defer_list[(size_t)shard * a.defer_cap_s + idx] = id;
+        else a.fcnt->overflow = 1;
+    }
+}
+
+// Geometry of a stage-2 launch: rays per wavefront from the (largest shard of the) list.
+struct NarrowGeom {
+    uint32_t R, kmax, nmax;
+};
+__device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
+    uint32_t v = a.fcnt->n_defer[ph][lane_id() % RTU_SHARDS];
+    if (v > a.defer_cap_s) v = a.defer_cap_s;
+    uint32_t sum = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o > v ? o : v;
+        sum += (uint32_t)__shfl_xor((int)sum, off);
+    }
+    NarrowGeom g;
+    g.nmax = v;
+    // enough wavefronts to fill 256 CUs several times over before widening them
+    g.R = sum > (1u << 20) ? 64u : sum > (1u << 18) ? 32u : sum > (1u << 15) ? 16u : 8u;
+    if (a.frame.reserved[0] > 0) g.R = (uint32_t)a.frame.reserved[0];  // diagnostic override
+    g.kmax = (v + g.R - 1u) / g.R;
+    return g;
+}
+
+// ---- the primary ray of one pixel -------------------------------------------------------
+template <int STACK, bool STATS, bool DEFER>
+__device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t pix, uint32_t shard,
+                                              uint32_t* stk, Counters& cnt, bool& deferred) {
     const DevScene& s = a.scene;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;  // whole wavefront
-    const uint32_t band_local = tile / a.tiles_x;
-    const uint32_t tx = tile - band_local * a.tiles_x;
-    const int x = (int)(tx * 8 + (lane & 7));
-    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
-    const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
-    const bool valid = x < a.frame.width && y < a.frame.height;
-    Counters cnt = {};
     bool want = false;
     Hit h;
     fresh_hit(h, RTU_BIGFLOAT);
@@ -143,24 +177,25 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     ray.p = ld3(a.frame.cam_pos);
     ray.dir = mk3(0, 0, 0);
     int mid = -1;
-    const uint32_t pix = (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+    deferred = false;
     if (valid) {
         // RenderFunctions.cpp:258-268 (pixel centre), :97
         f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS>(s, ray, false, h, s_stack + lane, cnt);
-        if (!hit) {
-            f3 bg = ld3(s.background);  // :145
-            a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
-        } else {
-            RTU_CNT(prim_hit);
-            mid = as_const(s.nodes)[h.node].material_id;
-            if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
-            else want = true;
+        bool hit = trace<STACK, STATS, !STATS, DEFER>(s, ray, false, h, stk, cnt, deferred);
+        if (!deferred) {
+            if (!hit) {
+                f3 bg = ld3(s.background);  // :145
+                a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
+            } else {
+                RTU_CNT(prim_hit);
+                mid = as_const(s.nodes)[h.node].material_id;
+                if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
+                else want = true;
+            }
         }
     }
-    const uint32_t shard = tile % RTU_SHARDS;
     uint32_t idx = wave_append(&a.fcnt->n_frames[0][shard], want);
     if (want) {
         const LevelBuffers& lv = a.lv[0];
@@ -174,15 +209,120 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
             a.fcnt->overflow = 1;
         }
     }
+}
+
+// stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
+template <int STACK, bool STATS>
+__global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
+    __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
+    uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;  // whole wavefront
+    const uint32_t band_local = tile / a.tiles_x;
+    const uint32_t tx = tile - band_local * a.tiles_x;
+    const int x = (int)(tx * 8 + (lane & 7));
+    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
+    const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
+    const bool valid = x < a.frame.width && y < a.frame.height;
+    const uint32_t pix = (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+    const uint32_t shard = tile % RTU_SHARDS;
+    Counters cnt = {};
+    bool deferred;
+    primary_pixel<STACK, STATS, !STATS>(a, valid, x, y, pix, shard, stk, cnt, deferred);
+    if (!STATS) defer_push(a, 0, shard, deferred, pix);
     flush_counters<STATS>(a, cnt);
 }
 
-// ------------------------------------------------------------------------------------
-// One lane = one ray of one frame. Work is laid out slot-major in chunks of 64 frames.
-template <int STACK, bool STATS>
-__global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel) {
+// stage 2: the deferred pixels, R per wavefront
+template <int STACK>
+__global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
     __shared__ uint32_t s_stack[STACK * 64];
+    const uint32_t lane = threadIdx.x;
+    const NarrowGeom g = narrow_geom(a, 0);
+    const uint32_t chunks = g.kmax * RTU_SHARDS;
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        uint32_t ns = a.fcnt->n_defer[0][shard];
+        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t e = k * g.R + lane;
+        const bool valid = lane < g.R && e < ns;
+        uint32_t pix = 0;
+        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        const uint32_t ly = pix / (uint32_t)a.frame.width;
+        const int x = (int)(pix - ly * (uint32_t)a.frame.width);
+        const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
+        bool deferred;
+        primary_pixel<STACK, false, false>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
+    }
+}
+
+// ---- one ray of one frame ------------------------------------------------------------------
+// slot < nsl: shadow ray of non-ambient light `slot`; else secondary ray slot - nsl.
+// Returns true if the ray was deferred (DEFER only).
+template <int STACK, bool STATS, bool DEFER>
+__device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt) {
     const DevScene& s = a.scene;
+    const LevelBuffers& lv = a.lv[L];
+    const float4 fa = lv.fa[f];
+    const uint32_t info = __float_as_uint(fa.w);
+    const f3 p = mk3(fa.x, fa.y, fa.z);
+    Ray r;
+    r.p = p;
+    float tmax = RTU_BIGFLOAT;
+    const bool is_shadow = slot < a.nsl;
+    const int sslot = (int)slot - (int)a.nsl;
+    if (is_shadow) {
+        // ---- shadow ray (lightFunctions.cpp:27-37, 75-78; lights.h:48)
+        if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) return false;
+        const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[slot]];
+        f3 lvec = ld3(l.vec);
+        if (l.type == RTU_LIGHT_DIRECT) {
+            r.dir = -lvec;
+        } else {
+            r.dir = norm3(lvec - p);
+            tmax = len3(lvec - p);
+        }
+        RTU_CNT(shd);
+    } else {
+        // ---- secondary rays of MtlBlinn::Shade (mtlFunctions.cpp:160-229, 239, 273-283)
+        if (sslot == SLOT_MAIN && (!(sel & SEL_MAIN) || !(info & RTU_FI_MAIN))) return false;
+        if (sslot == SLOT_A && (!(sel & SEL_A) || !(info & RTU_FI_MAIN) || (info & RTU_FI_TIR))) return false;
+        if (sslot == SLOT_C && (!(sel & SEL_C) || !(info & RTU_FI_C))) return false;
+        if (sslot == SLOT_A && (sel & SEL_A_NEEDS_B)) {
+            // counting variant: the Fresnel ray exists only if the refracted ray hit (:234)
+            const float4 b1 = lv.fslot[((size_t)f * 3 + SLOT_MAIN) * 2 + 1];
+            if (!(__float_as_uint(b1.w) & 1u)) return false;
+        }
+        const float4 fb = lv.fb[f], fc = lv.fc[f];
+        const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+        const float ior = as_const(s.materials)[info & RTU_FI_MTL_MASK].ior;
+        r.dir = secondary_dir(sslot, info, dir, p, N, ior);
+        RTU_CNT(sec);
+    }
+    Hit h;
+    fresh_hit(h, tmax);
+    bool deferred;
+    const bool hit = trace<STACK, STATS, !STATS, DEFER>(s, r, is_shadow, h, stk, cnt, deferred);
+    if (DEFER && deferred) return true;
+    if (is_shadow) {
+        lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
+    } else {
+        int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
+        // packed: bit0 hit, bit1 front, bits 2.. material id + 1 (0 = node without material)
+        uint32_t packed = (hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2);
+        float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
+        slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+        slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
+    }
+    return false;
+}
+
+// stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
+template <int STACK, bool STATS>
+__global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
+    __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
     const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;  // 64-frame chunks per shard
@@ -195,61 +335,32 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel) {
         const uint32_t cc = c - slot * chunks;
         const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
         const uint32_t fl = k * 64u + lane;
-        if (fl >= shard_count(a, L, shard)) continue;
+        const bool active = fl < shard_count(a, L, shard);
         const uint32_t f = shard * lv.cap_s + fl;
-        const float4 fa = lv.fa[f];
-        const uint32_t info = __float_as_uint(fa.w);
-        const f3 p = mk3(fa.x, fa.y, fa.z);
-        if (slot < a.nsl) {
-            // ---- shadow ray of non-ambient light `slot` (lightFunctions.cpp:27-37, 75-78; lights.h:48)
-            if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) continue;
-            const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[slot]];
-            f3 lvec = ld3(l.vec);
-            Ray r;
-            r.p = p;
-            float tmax;
-            if (l.type == RTU_LIGHT_DIRECT) {
-                r.dir = -lvec;
-                tmax = RTU_BIGFLOAT;
-            } else {
-                r.dir = norm3(lvec - p);
-                tmax = len3(lvec - p);
-            }
-            RTU_CNT(shd);
-            Hit h;
-            fresh_hit(h, tmax);
-            bool hit = trace<STACK, STATS, !STATS>(s, r, true, h, s_stack + lane, cnt);
-            lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
-        } else {
-            // ---- secondary rays of MtlBlinn::Shade (mtlFunctions.cpp:160-229, 239, 273-283)
-            const int sslot = (int)(slot - a.nsl);
-            if (sslot == SLOT_MAIN && (!(sel & SEL_MAIN) || !(info & RTU_FI_MAIN))) continue;
-            if (sslot == SLOT_A && (!(sel & SEL_A) || !(info & RTU_FI_MAIN) || (info & RTU_FI_TIR))) continue;
-            if (sslot == SLOT_C && (!(sel & SEL_C) || !(info & RTU_FI_C))) continue;
-            if (sslot == SLOT_A && (sel & SEL_A_NEEDS_B)) {
-                // counting variant: the Fresnel ray exists only if the refracted ray hit (:234)
-                const float4 b1 = lv.fslot[((size_t)f * 3 + SLOT_MAIN) * 2 + 1];
-                if (!(__float_as_uint(b1.w) & 1u)) continue;
-            }
-            const float4 fb = lv.fb[f], fc = lv.fc[f];
-            const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-            const float ior = as_const(s.materials)[info & RTU_FI_MTL_MASK].ior;
-            Ray r;
-            r.p = p;
-            r.dir = secondary_dir(sslot, info, dir, p, N, ior);
-            RTU_CNT(sec);
-            Hit h;
-            fresh_hit(h, RTU_BIGFLOAT);
-            bool hit = trace<STACK, STATS, !STATS>(s, r, false, h, s_stack + lane, cnt);
-            int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
-            // packed: bit0 hit, bit1 front, bits 2.. material id + 1 (0 = node without material)
-            uint32_t packed = (hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2);
-            float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
-            slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-            slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
-        }
+        bool deferred = false;
+        if (active) deferred = frame_ray<STACK, STATS, !STATS>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
+        if (!STATS) defer_push(a, ph, shard, deferred, (slot << 28) | f);
     }
     flush_counters<STATS>(a, cnt);
+}
+
+// stage 2: the deferred rays of phase `ph`, R per wavefront
+template <int STACK>
+__global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
+    __shared__ uint32_t s_stack[STACK * 64];
+    const uint32_t lane = threadIdx.x;
+    const NarrowGeom g = narrow_geom(a, ph);
+    const uint32_t chunks = g.kmax * RTU_SHARDS;
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        uint32_t ns = a.fcnt->n_defer[ph][shard];
+        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t e = k * g.R + lane;
+        if (lane >= g.R || e >= ns) continue;
+        const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        frame_ray<STACK, false, false>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -474,17 +585,25 @@ template <int STACK>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
-    const dim3 gridT(16384), gridF(4096);  // persistent grids: 64-frame chunks are strided over them
+    const dim3 gridT(16384), gridN(16384), gridF(4096);  // persistent grids: chunks are strided over them
     if (n_tiles == 0) return (int)hipSuccess;
-    if (stats) hipLaunchKernelGGL((k_primary<STACK, true>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, a, n_tiles);
-    else hipLaunchKernelGGL((k_primary<STACK, false>), dim3((n_tiles + 3) / 4), dim3(256), 0, stream, a, n_tiles);
+    const dim3 gridP((n_tiles + 3) / 4);
+    if (stats) {
+        hipLaunchKernelGGL((k_primary<STACK, true>), gridP, dim3(256), 0, stream, a, n_tiles);
+    } else {
+        hipLaunchKernelGGL((k_primary<STACK, false>), gridP, dim3(256), 0, stream, a, n_tiles);
+        hipLaunchKernelGGL((k_primary2<STACK>), gridN, block, 0, stream, a);
+    }
     for (int L = 0; L < levels; L++) {
+        const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
-            hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C));
-            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B));
+            hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
+            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
             hipLaunchKernelGGL((k_consume<true>), gridF, block, 0, stream, a, L);
         } else {
-            hipLaunchKernelGGL((k_trace<STACK, false>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C));
+            const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
+            hipLaunchKernelGGL((k_trace<STACK, false>), gridT, block, 0, stream, a, L, sel, ph);
+            hipLaunchKernelGGL((k_trace2<STACK>), gridN, block, 0, stream, a, L, sel, ph);
             hipLaunchKernelGGL((k_consume<false>), gridF, block, 0, stream, a, L);
         }
     }

@@ -31,6 +31,8 @@ struct RtuContext {
     uint32_t level_nsl = 0;
     uint32_t cap_scale = 1;         // capacity of levels >= 1 = cap_scale * pixels (doubled on overflow)
     FrameCounters* fcnt = nullptr;
+    uint32_t* defer_list = nullptr;
+    uint32_t  defer_cap_s = 0;
     uint32_t nsl = 0;
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
     float4* fb = nullptr;
@@ -205,6 +207,10 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
         if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
         lv.cap_s = (uint32_t)cap_s;
     }
+    // defer list: at most every ray of the largest phase (all slots of the largest level)
+    size_t dcap_s = (size_t)ctx->lv[1].cap_s * (ctx->nsl + 3);
+    if ((rc = alloc_level(ctx, &ctx->defer_list, dcap_s * RTU_SHARDS)) != RTU_OK) return rc;
+    ctx->defer_cap_s = (uint32_t)dcap_s;
     ctx->level_cap0 = pixels;
     ctx->level_nsl = ctx->nsl;
     return RTU_OK;
@@ -227,6 +233,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.out = d_out;
     memcpy(a.lv, ctx->lv, sizeof a.lv);
     a.fcnt = ctx->fcnt;
+    a.defer_list = ctx->defer_list;
+    a.defer_cap_s = ctx->defer_cap_s;
     a.counters = stats ? ctx->counters : nullptr;
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;

@@ -103,6 +103,7 @@ struct LevelBuffers {
 
 struct FrameCounters {
     uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS];
+    uint32_t n_defer[RTU_MAX_LEVELS + 1][RTU_SHARDS];  // phase 0 = primary rays, phase 1+L = rays of level L
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more
     uint32_t pad[3];
 };
@@ -113,6 +114,9 @@ struct KernelArgs {
     float4*      out;               // shard rows * width
     LevelBuffers lv[RTU_MAX_LEVELS];
     FrameCounters* fcnt;
+    uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
+    uint32_t     defer_cap_s;
+    uint32_t     pad0;
     unsigned long long* counters;   // 11 x u64 (RtuStats order) or nullptr
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights

@@ -222,8 +222,16 @@ __device__ __forceinline__ TriRec load_tri(const RTU_CONST DevMesh& mesh, uint32
     t.r0 = p[0]; t.r1 = p[1]; t.r2 = p[2]; t.r3 = p[3];
     return t;
 }
+// The accepted triangle with the smallest t wins (strict `t < hInfo.z`, earlier triangle on a
+// tie). Its interpolated point and normal (:321-324) depend only on (face, barycentrics), so
+// they are evaluated ONCE, for the final winner, after the walk (three dependent global
+// loads per accepted candidate otherwise; shadow rays never need them).
+struct TriWin {
+    uint32_t slot;
+    f3 bc;
+};
 template <bool STATS>
-__device__ __forceinline__ bool tri_hit(const RTU_CONST DevMesh& mesh, uint32_t slot, const TriRec& T, const Ray& ray, Hit& h, Counters& cnt) {
+__device__ __forceinline__ bool tri_hit(const TriRec& T, uint32_t slot, const Ray& ray, Hit& h, TriWin& win, Counters& cnt) {
     RTU_CNT(tri);
     const f3 A = mk3(T.r0.x, T.r0.y, T.r0.z);
     const f3 N = mk3(T.r0.w, T.r1.x, T.r1.y);
@@ -245,12 +253,10 @@ __device__ __forceinline__ bool tri_hit(const RTU_CONST DevMesh& mesh, uint32_t 
             const float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
             if (BC1 > 0 && BC2 > 0 && BC3 > 0 && BC1 < 1 && BC2 < 1 && BC3 < 1) {
                 RTU_CNT(acc);
-                const f3 bc = mk3(BC3, BC1, BC2);
-                const uint32_t face = mesh.elements[slot];
+                win.slot = slot;
+                win.bc = mk3(BC3, BC1, BC2);
                 h.front = dn < 0;
-                h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, bc));
                 h.z = t;
-                h.p = interp(mesh.v, mesh.f + 3 * face, bc);
                 return true;
             }
         }
@@ -295,6 +301,9 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
         cullK = 1.0f + 1e-3f + 8e-6f * (len3(ray.dir) / mn);  // +inf for an axis-parallel ray: never cull
     }
     bool hitResult = false;
+    TriWin win;
+    win.slot = 0;
+    win.bc = mk3(0, 0, 0);
     int sp = 0;
     float4 r0 = mesh.bvh[2], r1 = mesh.bvh[3];  // root = node 1 (cyBVH.h:76)
     uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
@@ -359,7 +368,7 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             for (uint32_t i = 0; i < count; i++) {
                 TriRec nxt = cur;
                 if (i + 1 < count) nxt = load_tri(mesh, index + i + 1);
-                hitResult |= tri_hit<STATS>(mesh, index + i, cur, ray, h, cnt);
+                hitResult |= tri_hit<STATS>(cur, index + i, ray, h, win, cnt);
                 cur = nxt;
             }
             if (CULL && shadow && hitResult) {
@@ -373,6 +382,12 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
                 alive = false;
             }
         }
+    }
+    if (hitResult && !shadow) {
+        // hInfo.N / hInfo.p of the winning triangle (:322, :324)
+        const uint32_t face = mesh.elements[win.slot];
+        h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
+        h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
     }
     return hitResult;
 }
@@ -388,11 +403,17 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
 // lanes casting shadow rays and lanes casting reflection / refraction rays walk
 // the scene together (better SIMD occupancy, a quarter of the code size of four
 // specialised copies — the kernel has to stay inside the instruction cache).
-template <int STACK, bool STATS, bool CULL>
-__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
+//
+// DEFER (stage 1 of a two-stage phase, see render_kernel.hip): the moment the ray passes
+// the bounding box of a mesh node the walk is abandoned and `deferred` is set; the caller
+// queues the ray for the narrow-wavefront stage-2 kernel, which walks the whole scene
+// again with DEFER=false. Rays that never touch a mesh complete in stage 1.
+template <int STACK, bool STATS, bool CULL, bool DEFER>
+__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred) {
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
     const RTU_CONST DevMesh* meshes = as_const(s.meshes);
     bool any = false;
+    deferred = false;
     Ray r0 = to_node(nodes[0], wr);  // ray inside the root node
     Ray rp = r0;                     // ray inside node `rp_node` (cached parent space)
     int rp_node = 0;
@@ -400,6 +421,7 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         const RTU_CONST DevNode& n = nodes[k];
         if (n.obj_type == RTU_OBJ_NONE) continue;
         if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
+        if (DEFER && deferred) continue;
         int parent = n.parent;
         Ray pr;
         if (parent < 0) {
@@ -419,7 +441,11 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         bool hit;
         if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h);
         else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h);
-        else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
+        else if (DEFER) {
+            const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
+            if (box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) deferred = true;
+            hit = false;
+        } else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
         if (hit) {
             any = true;
             if (!shadow) {

@@ -159,16 +159,17 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     NarrowGeom g;
     g.nmax = v;
     // enough wavefronts to fill 256 CUs several times over before widening them
-    g.R = sum > (1u << 20) ? 64u : sum > (1u << 18) ? 32u : sum > (1u << 15) ? 16u : 8u;
-    if (a.frame.reserved[0] > 0) g.R = (uint32_t)a.frame.reserved[0];  // diagnostic override
+    // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
+    g.R = sum > (uint32_t)(a.frame.reserved[0] > 0 ? a.frame.reserved[0] : 200000) ? 64u : 8u;
     g.kmax = (v + g.R - 1u) / g.R;
     return g;
 }
 
 // ---- the primary ray of one pixel -------------------------------------------------------
-template <int STACK, bool STATS, bool DEFER>
+template <int STACK, bool STATS, bool DEFER, bool COOP = false>
 __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t pix, uint32_t shard,
-                                              uint32_t* stk, Counters& cnt, bool& deferred) {
+                                              uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
+                                              const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
     bool want = false;
     Hit h;
@@ -183,8 +184,8 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER>(s, ray, false, h, stk, cnt, deferred);
-        if (!deferred) {
+        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+        if (!deferred && leader) {
             if (!hit) {
                 f3 bg = ld3(s.background);  // :145
                 a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
@@ -234,35 +235,80 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     flush_counters<STATS>(a, cnt);
 }
 
-// stage 2: the deferred pixels, R per wavefront
+// Stage the top of every mesh's BVH (BFS order) into the workgroup's LDS node area.
+template <int STACK>
+__device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nodes) {
+    const RTU_CONST DevMesh* meshes = as_const(a.scene.meshes);
+    for (uint32_t m = 0; m < a.n_meshes; m++) {
+        const float4* src = meshes[m].bvh;
+        const uint32_t n = meshes[m].lds_nodes * 2u, off = meshes[m].lds_off;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_nodes[off + i] = src[i];
+    }
+    __syncthreads();
+}
+
+// stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
 template <int STACK>
 __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, 0);
-    const uint32_t chunks = g.kmax * RTU_SHARDS;
+    if (g.R == 8u) return;  // short list: k_primary2c takes it
+    const uint32_t kmax = (g.nmax + 63u) / 64u;
+    const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         uint32_t ns = a.fcnt->n_defer[0][shard];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * g.R + lane;
-        const bool valid = lane < g.R && e < ns;
+        const uint32_t e = k * 64u + lane;
+        const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
         const uint32_t ly = pix / (uint32_t)a.frame.width;
         const int x = (int)(pix - ly * (uint32_t)a.frame.width);
         const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
         bool deferred;
-        primary_pixel<STACK, false, false>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
+        primary_pixel<STACK, false, false, false>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
+    }
+}
+
+// stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
+// (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
+template <int STACK>
+__global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
+    __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
+    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
+    const NarrowGeom g = narrow_geom(a, 0);
+    if (g.R != 8u) return;
+    stage_nodes<STACK>(a, s_nodes);
+    const uint32_t grp = threadIdx.x >> 3;
+    const bool leader = (threadIdx.x & 7u) == 0;
+    const uint32_t kmax = (g.nmax + RTU_COOP_GROUPS - 1u) / RTU_COOP_GROUPS;
+    const uint32_t chunks = kmax * RTU_SHARDS;
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        uint32_t ns = a.fcnt->n_defer[0][shard];
+        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t e = k * RTU_COOP_GROUPS + grp;
+        const bool valid = e < ns;
+        uint32_t pix = 0;
+        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        const uint32_t ly = pix / (uint32_t)a.frame.width;
+        const int x = (int)(pix - ly * (uint32_t)a.frame.width);
+        const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
+        bool deferred;
+        primary_pixel<STACK, false, false, true>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
 // ---- one ray of one frame ------------------------------------------------------------------
 // slot < nsl: shadow ray of non-ambient light `slot`; else secondary ray slot - nsl.
 // Returns true if the ray was deferred (DEFER only).
-template <int STACK, bool STATS, bool DEFER>
-__device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt) {
+template <int STACK, bool STATS, bool DEFER, bool COOP = false>
+__device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt,
+                                          bool leader = true, const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const float4 fa = lv.fa[f];
@@ -304,8 +350,9 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     Hit h;
     fresh_hit(h, tmax);
     bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER>(s, r, is_shadow, h, stk, cnt, deferred);
+    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
     if (DEFER && deferred) return true;
+    if (!leader) return false;
     if (is_shadow) {
         lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
     } else {
@@ -344,22 +391,48 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
     flush_counters<STATS>(a, cnt);
 }
 
-// stage 2: the deferred rays of phase `ph`, R per wavefront
+// stage 2, long lists: one lane per deferred ray
 template <int STACK>
 __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, ph);
-    const uint32_t chunks = g.kmax * RTU_SHARDS;
+    if (g.R == 8u) return;  // short list: k_trace2c takes it
+    const uint32_t kmax = (g.nmax + 63u) / 64u;
+    const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         uint32_t ns = a.fcnt->n_defer[ph][shard];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * g.R + lane;
-        if (lane >= g.R || e >= ns) continue;
+        const uint32_t e = k * 64u + lane;
+        if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<STACK, false, false>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
+        frame_ray<STACK, false, false, false>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
+    }
+}
+
+// stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
+template <int STACK>
+__global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
+    __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
+    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
+    const NarrowGeom g = narrow_geom(a, ph);
+    if (g.R != 8u) return;
+    stage_nodes<STACK>(a, s_nodes);
+    const uint32_t grp = threadIdx.x >> 3;
+    const bool leader = (threadIdx.x & 7u) == 0;
+    const uint32_t kmax = (g.nmax + RTU_COOP_GROUPS - 1u) / RTU_COOP_GROUPS;
+    const uint32_t chunks = kmax * RTU_SHARDS;
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
+        uint32_t ns = a.fcnt->n_defer[ph][shard];
+        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t e = k * RTU_COOP_GROUPS + grp;
+        if (e >= ns) continue;
+        const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        frame_ray<STACK, false, false, true>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
@@ -585,13 +658,16 @@ template <int STACK>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
-    const dim3 gridT(16384), gridN(16384), gridF(4096);  // persistent grids: chunks are strided over them
+    // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
+    // workgroups, so the deeper, usually sparse levels get smaller grids
+    const dim3 gridT(8192), gridN(16384), gridS(8192), gridF(2048), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
     if (stats) {
         hipLaunchKernelGGL((k_primary<STACK, true>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         hipLaunchKernelGGL((k_primary<STACK, false>), gridP, dim3(256), 0, stream, a, n_tiles);
+        hipLaunchKernelGGL((k_primary2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
         hipLaunchKernelGGL((k_primary2<STACK>), gridN, block, 0, stream, a);
     }
     for (int L = 0; L < levels; L++) {
@@ -602,12 +678,13 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_consume<true>), gridF, block, 0, stream, a, L);
         } else {
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
-            hipLaunchKernelGGL((k_trace<STACK, false>), gridT, block, 0, stream, a, L, sel, ph);
-            hipLaunchKernelGGL((k_trace2<STACK>), gridN, block, 0, stream, a, L, sel, ph);
+            hipLaunchKernelGGL((k_trace<STACK, false>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
+            hipLaunchKernelGGL((k_trace2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
+            hipLaunchKernelGGL((k_trace2<STACK>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
             hipLaunchKernelGGL((k_consume<false>), gridF, block, 0, stream, a, L);
         }
     }
-    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL(k_combine, gridF, block, 0, stream, a, L);
+    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL(k_combine, gridC, block, 0, stream, a, L);
     return (int)hipGetLastError();
 }
 

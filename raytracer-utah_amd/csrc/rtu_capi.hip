@@ -33,6 +33,8 @@ struct RtuContext {
     FrameCounters* fcnt = nullptr;
     uint32_t* defer_list = nullptr;
     uint32_t  defer_cap_s = 0;
+    bool     any_recursive_material = true;
+    uint32_t n_meshes = 0;
     uint32_t nsl = 0;
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
     float4* fb = nullptr;
@@ -230,6 +232,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     memset(&a, 0, sizeof a);
     a.scene = ctx->dscene;
     a.frame = *frame;
+    if (!ctx->any_recursive_material) a.frame.max_bounce = 0;  // no reflection/refraction anywhere: Shade() never recurses
     a.out = d_out;
     memcpy(a.lv, ctx->lv, sizeof a.lv);
     a.fcnt = ctx->fcnt;
@@ -238,6 +241,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.counters = stats ? ctx->counters : nullptr;
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
+    a.n_meshes = ctx->n_meshes;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
     hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -384,7 +388,28 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             if (bn.bmin[0] > bn.bmax[0] || bn.bmin[1] > bn.bmax[1] || bn.bmin[2] > bn.bmax[2]) d.any_empty_box = 1;
         }
         static_assert(sizeof(RtuBvhNode) == 2 * sizeof(float4), "BVH node is two float4");
-        if ((rc = upload(ctx, reinterpret_cast<const float4*>(m.bvh), (size_t)m.n_bvh_nodes * 2, &d.bvh)) != RTU_OK) return rc;
+        // Renumber the nodes breadth-first (sibling pairs stay adjacent, the root stays node 1):
+        // same tree, same traversal, but the top levels become the first entries of the
+        // array, which is what the cooperative kernels stage into LDS.
+        std::vector<RtuBvhNode> bfs(m.n_bvh_nodes);
+        memset(bfs.data(), 0, bfs.size() * sizeof(RtuBvhNode));
+        {
+            std::vector<std::pair<uint32_t, uint32_t>> queue;  // (old id, new id)
+            queue.push_back({1u, 1u});
+            uint32_t next_free = 2;
+            for (size_t qi = 0; qi < queue.size(); qi++) {
+                auto [oldId, newId] = queue[qi];
+                RtuBvhNode nn = m.bvh[oldId];
+                if (nn.count == 0) {
+                    queue.push_back({nn.index, next_free});
+                    queue.push_back({nn.index + 1, next_free + 1});
+                    nn.index = next_free;
+                    next_free += 2;
+                }
+                bfs[newId] = nn;
+            }
+        }
+        if ((rc = upload(ctx, reinterpret_cast<const float4*>(bfs.data()), (size_t)m.n_bvh_nodes * 2, &d.bvh)) != RTU_OK) return rc;
         if ((rc = upload(ctx, tri.data(), tri.size(), &d.tri)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.elements, (size_t)m.n_elements, &d.elements)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
@@ -396,6 +421,22 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         d.n_bvh_nodes = m.n_bvh_nodes;
         d.n_elements = m.n_elements;
         if (m.bvh_depth > stack_needed) stack_needed = m.bvh_depth;
+    }
+
+    // LDS node areas of the cooperative kernels (RTU_LDS_NODE_F4 of the STACK variant that
+    // rtu_launch_frame will pick), handed out in mesh order
+    {
+        uint32_t stack_sel = stack_needed <= 16 ? 16 : stack_needed <= 24 ? 24 : stack_needed <= 32 ? 32 : RTU_MAX_BVH_STACK;
+        uint32_t budget = (uint32_t)RTU_LDS_NODE_F4(stack_sel) / 2;  // nodes
+        uint32_t used = 0;
+        for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
+            uint32_t take = s->meshes[mi].n_bvh_nodes;
+            if (take > budget - used) take = budget - used;
+            take &= ~1u;  // whole sibling pairs
+            meshes[mi].lds_nodes = take;
+            meshes[mi].lds_off = used * 2;
+            used += take;
+        }
     }
 
     DevScene ds;
@@ -413,6 +454,13 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
     ctx->cap_scale = 1;
+    ctx->n_meshes = s->n_meshes;
+    ctx->any_recursive_material = false;
+    for (uint32_t i = 0; i < s->n_materials; i++) {
+        const RtuMaterial& mm = s->materials[i];
+        for (int k = 0; k < 3; k++)
+            if (mm.reflection[k] != 0 || mm.refraction[k] != 0) ctx->any_recursive_material = true;
+    }
     ctx->bvh_stack_needed = stack_needed;
     ctx->has_scene = true;
     return RTU_OK;

@@ -39,6 +39,8 @@ struct DevMesh {
     float    bmin[3], bmax[3];
     uint32_t n_bvh_nodes, n_elements;
     uint32_t any_empty_box;     // some BVH box has min > max (cannot come from triangles)
+    uint32_t lds_nodes;         // nodes [0, lds_nodes) are staged in LDS by the cooperative kernels (BFS order: the top of the tree)
+    uint32_t lds_off;           // their offset in the block's LDS node area, in float4
     uint32_t pad;
 };
 
@@ -99,6 +101,13 @@ struct LevelBuffers {
 // ~88 atomics/us on MI355X (32 400 tiles => ~370 us, measured), so every level's arrays
 // are split into RTU_SHARDS independent regions, each with its own counter; a wavefront
 // appends to the shard of its own index, which keeps the regions balanced.
+// LDS node area of the cooperative (8 lanes per ray, 1024 threads per workgroup) kernels:
+// the whole 160 KB of a CU minus the 128 per-ray traversal stacks.
+#define RTU_COOP_THREADS 1024
+#define RTU_COOP_GROUPS  (RTU_COOP_THREADS / 8)
+#define RTU_LDS_BYTES    163840
+#define RTU_LDS_NODE_F4(STACK) ((RTU_LDS_BYTES - RTU_COOP_GROUPS * (STACK) * 4) / 16)
+
 #define RTU_SHARDS 64
 
 struct FrameCounters {
@@ -121,6 +130,8 @@ struct KernelArgs {
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights
     int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
+    uint32_t     n_meshes;
+    uint32_t     pad1;
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine

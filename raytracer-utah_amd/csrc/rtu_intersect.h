@@ -283,7 +283,8 @@ __device__ __forceinline__ bool tri_hit(const TriRec& T, uint32_t slot, const Ra
 //    DESIGN.md "Culling margin"): every triangle in it would fail `t < hInfo.z`
 //    (objFunctions.cpp:270), so skipping it cannot change any output bit.
 template <int STACK, bool STATS, bool CULL>
-__device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt) {
+__device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+                                         const uint32_t stride = 64) {
     if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
     RTU_CNT(mesh);
     // The reference's slab test has special cases for an exactly-zero direction component
@@ -345,7 +346,7 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             uint32_t next;
             if (nearV) {
                 if (farV) {
-                    if (sp < STACK) stk[sp * 64] = farP;
+                    if (sp < STACK) stk[sp * stride] = farP;
                     sp++;
                 }
                 next = nearP;
@@ -353,7 +354,7 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
                 next = farP;
             } else if (sp > 0) {
                 sp--;
-                next = stk[sp * 64];
+                next = stk[sp * stride];
             } else {
                 alive = false;
                 next = 1u << 28;  // leave the inner loop
@@ -375,7 +376,7 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
                 alive = false;
             } else if (sp > 0) {
                 sp--;
-                uint32_t next = stk[sp * 64];
+                uint32_t next = stk[sp * stride];
                 index = next & 0x0FFFFFFFu;
                 count = next >> 28;
             } else {
@@ -385,6 +386,171 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
     }
     if (hitResult && !shadow) {
         // hInfo.N / hInfo.p of the winning triangle (:322, :324)
+        const uint32_t face = mesh.elements[win.slot];
+        h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
+        h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
+    }
+    return hitResult;
+}
+
+// ---------------------------------------------------------------------------
+// COOPERATIVE BVH WALK: eight lanes per ray.
+//
+// Measured (profiles/r01_*): a lone wavefront issues one VALU instruction per ~4.5
+// cycles, an inner BVH step is ~130 instructions and a leaf round up to 4 x ~110, so a
+// ray that needs 100+ steps holds its wavefront — and, being the slowest, the whole
+// phase — for hundreds of microseconds while the chip idles. The steps of ONE ray are
+// inherently sequential (near-first order), but the work INSIDE a step is not:
+//   inner step: 2 children x 3 axes x 2 planes = 12 exact quotients -> lanes 0..5 of the
+//               group do one (child, axis) slab each, lanes 6,7 fetch the child words;
+//   leaf round: up to 8 triangles -> one triangle per lane, then a min-t reduction with
+//               the lower element index winning a tie (= the reference's strict `t < z`
+//               applied in element order, objFunctions.cpp:270,394-396).
+// All eight lanes hold the same ray and keep identical copies of the walk state (h.z,
+// winner, stack pointer), so every lane takes the same branches; values move between lanes
+// with ds_swizzle / ds_bpermute (no LDS memory). Same visiting order, same float
+// operations, same results as mesh_hit — only the latency per step drops ~3x.
+__device__ __forceinline__ float grp_bcast(float v, int srcSub) {  // value of sub-lane srcSub of my 8-lane group
+    int r;
+    switch (srcSub) {  // ds_swizzle bitmask mode: lane' = (lane & 0x18) | srcSub
+        case 0: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (0 << 5)); break;
+        case 3: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (3 << 5)); break;
+        case 6: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (6 << 5)); break;
+        default: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (7 << 5)); break;
+    }
+    return __int_as_float(r);
+}
+template <int M>
+__device__ __forceinline__ int grp_xor(int v) {  // value of lane ^ M
+    return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));
+}
+
+template <int STACK, bool CULL>
+__device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+                                              const uint32_t stride, const float4* lds_nodes) {
+    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
+    const bool zeroDir = ray.dir.x == 0 || ray.dir.y == 0 || ray.dir.z == 0;
+    if (__any(zeroDir) || mesh.any_empty_box)  // literal special-case form: every lane of the group walks alone
+        return mesh_hit<STACK, false, CULL>(mesh, ray, shadow, h, stk, cnt, stride);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & 7u;
+    // role of this lane in an inner step
+    const uint32_t child = sub >= 3u ? 1u : 0u;
+    const uint32_t axis = sub < 6u ? sub - 3u * child : 0u;
+    const uint32_t o0 = sub < 6u ? child * 8u + axis : (sub == 6u ? 3u : 11u);       // bmin[axis] | child.index
+    const uint32_t o1 = sub < 6u ? child * 8u + 4u + axis : (sub == 6u ? 7u : 15u);  // bmax[axis] | child.count
+    const float p_a = axis == 0 ? ray.p.x : axis == 1 ? ray.p.y : ray.p.z;
+    const float d_a = axis == 0 ? ray.dir.x : axis == 1 ? ray.dir.y : ray.dir.z;
+    const double rcp_a = 1.0 / (double)d_a;
+    float cullK = 0.0f;
+    if (CULL) {
+        float ax = fabsf(ray.dir.x), ay = fabsf(ray.dir.y), az = fabsf(ray.dir.z);
+        float mn = fminf(ax, fminf(ay, az));
+        cullK = 1.0f + 1e-3f + 8e-6f * (len3(ray.dir) / mn);
+    }
+    bool hitResult = false;
+    TriWin win;
+    win.slot = 0;
+    win.bc = mk3(0, 0, 0);
+    int sp = 0;
+    float4 r0 = mesh.bvh[2], r1 = mesh.bvh[3];  // root = node 1
+    uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
+    bool alive = true;
+    while (alive) {
+        while (alive && count == 0) {  // inner node: all eight lanes cooperate
+            float w0, w1;
+            if (index < mesh.lds_nodes) {  // the top of the tree lives in LDS (staged once per workgroup)
+                const float* pair = reinterpret_cast<const float*>(lds_nodes + mesh.lds_off + 2 * index);
+                w0 = pair[o0]; w1 = pair[o1];
+            } else {
+                const float* pair = reinterpret_cast<const float*>(mesh.bvh + 2 * index);
+                w0 = pair[o0]; w1 = pair[o1];
+            }
+            // lanes 0..5: one slab (objFunctions.cpp:223-240)
+            float t0 = fdiv(w0 - p_a, rcp_a), t1 = fdiv(w1 - p_a, rcp_a);
+            const bool sw = t0 > t1;
+            const float a0 = sw ? t1 : t0, a1 = sw ? t0 : t1;
+            // lanes 0 and 3 gather y,z of their child: tEntry = max(max(x,y),z), tExit = min(min(x,y),z)
+            const float y0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x101, 0xF, 0xF, true));  // row_shl:1
+            const float z0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x102, 0xF, 0xF, true));  // row_shl:2
+            const float y1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x101, 0xF, 0xF, true));
+            const float z1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x102, 0xF, 0xF, true));
+            const float e = smax(smax(a0, y0), z0), x = smin(smin(a1, y1), z1);
+            float t = (e <= x && e < RTU_BIGFLOAT) ? (float)((double)e + 0.01) : RTU_BIGFLOAT;  // :516-521
+            bool v = t != RTU_BIGFLOAT;
+            if (CULL) v = v && !(e > h.z * cullK + 1e-4f);
+            const float pk = __uint_as_float(__float_as_uint(w0) | (__float_as_uint(w1) << 28));  // lanes 6,7
+            // every lane fetches both children's verdicts and decides identically
+            const float tA = grp_bcast(t, 0), tB = grp_bcast(t, 3);
+            const bool vA = grp_bcast(v ? 1.0f : 0.0f, 0) != 0.0f, vB = grp_bcast(v ? 1.0f : 0.0f, 3) != 0.0f;
+            const uint32_t pA = __float_as_uint(grp_bcast(pk, 6)), pB = __float_as_uint(grp_bcast(pk, 7));
+            const bool firstIsC1 = tA <= tB;  // :361-389
+            const uint32_t nearP = firstIsC1 ? pA : pB, farP = firstIsC1 ? pB : pA;
+            const bool nearV = firstIsC1 ? vA : vB, farV = firstIsC1 ? vB : vA;
+            uint32_t next;
+            if (nearV) {
+                if (farV) {
+                    if (sp < STACK) stk[sp * stride] = farP;  // eight identical stores to the group's column
+                    sp++;
+                }
+                next = nearP;
+            } else if (farV) {
+                next = farP;
+            } else if (sp > 0) {
+                sp--;
+                next = stk[sp * stride];
+            } else {
+                alive = false;
+                next = 1u << 28;
+            }
+            index = next & 0x0FFFFFFFu;
+            count = next >> 28;
+        }
+        if (alive) {  // leaf: lane `sub` tests element index+sub
+            float myT = RTU_BIGFLOAT;
+            bool myFront = true;
+            TriWin myWin;
+            myWin.slot = index + sub;
+            myWin.bc = mk3(0, 0, 0);
+            if (sub < count) {
+                const TriRec T = load_tri(mesh, index + sub);
+                Hit hl = h;  // test against the best BEFORE this leaf; the reduction below applies the order
+                if (tri_hit<false>(T, index + sub, ray, hl, myWin, cnt)) { myT = hl.z; myFront = hl.front; }
+            }
+            // min t over the group, lower sub wins a tie: key = (t, sub)
+            int kt = __float_as_int(myT), ks = (int)sub;  // accepted t is positive: integer order == float order
+            {
+                int ot = grp_xor<1>(kt), os = grp_xor<1>(ks);
+                if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
+                ot = grp_xor<2>(kt); os = grp_xor<2>(ks);
+                if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
+                ot = grp_xor<4>(kt); os = grp_xor<4>(ks);
+                if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
+            }
+            const float bestT = __int_as_float(kt);
+            if (bestT < h.z) {  // somebody accepted a triangle (accepted t < h.z, misses carry BIGFLOAT >= h.z)
+                const int src = (int)(((lane & ~7u) + (uint32_t)ks) << 2);
+                h.z = bestT;
+                h.front = __builtin_amdgcn_ds_bpermute(src, myFront ? 1 : 0) != 0;
+                win.slot = index + (uint32_t)ks;
+                win.bc.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myWin.bc.x)));
+                win.bc.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myWin.bc.y)));
+                win.bc.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(myWin.bc.z)));
+                hitResult = true;
+            }
+            if (CULL && shadow && hitResult) {
+                alive = false;
+            } else if (sp > 0) {
+                sp--;
+                uint32_t next = stk[sp * stride];
+                index = next & 0x0FFFFFFFu;
+                count = next >> 28;
+            } else {
+                alive = false;
+            }
+        }
+    }
+    if (hitResult && !shadow) {
         const uint32_t face = mesh.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
@@ -408,8 +574,9 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
 // the bounding box of a mesh node the walk is abandoned and `deferred` is set; the caller
 // queues the ray for the narrow-wavefront stage-2 kernel, which walks the whole scene
 // again with DEFER=false. Rays that never touch a mesh complete in stage 1.
-template <int STACK, bool STATS, bool CULL, bool DEFER>
-__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred) {
+template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false>
+__device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
+                                      const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
     const RTU_CONST DevMesh* meshes = as_const(s.meshes);
     bool any = false;
@@ -445,7 +612,8 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
             const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
             if (box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) deferred = true;
             hit = false;
-        } else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
+        } else if (COOP) hit = mesh_hit_coop<STACK, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, stride, lds_nodes);
+        else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
         if (hit) {
             any = true;
             if (!shadow) {

@@ -5,7 +5,7 @@ pat = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof*/*/*_kernel_trace.c
 for f in sorted(glob.glob(pat)):
     rows = [r for r in csv.DictReader(open(f)) if "::k_" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "k_primary" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "k_primary<" in r["Kernel_Name"]]
     if not idx:
         continue
     last = rows[idx[-1]:]

@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (CPU share of one GPU)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
-    ap.add_argument("--narrow-r", type=int, default=0, help="diagnostic only: force rays per wavefront of the stage-2 kernels")
+    ap.add_argument("--coop-threshold", type=int, default=0, help="tuning: ray-list length below which stage 2 is cooperative (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -78,7 +78,7 @@ def main():
     ctx.upload(scene)  # inputs resident in HBM before any timing
 
     frame = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, max_bounce=args.max_bounce)
-    frame.reserved[0] = args.narrow_r
+    frame.coop_threshold = args.coop_threshold
     rows = pkg.shard_rows(frame)
     max_rows = pkg.hip.rtu_shard_max_rows(H, world)
     shard = torch.zeros(max_rows * W * 4, dtype=torch.float32, device=dev)

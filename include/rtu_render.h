@@ -56,7 +56,9 @@ typedef struct RtuFrameDesc {
     int32_t shard_rank, shard_count;  /* 0,1 for a single GPU */
     int32_t max_bounce;               /* 5, RenderFunctions.cpp:134 */
     int32_t collect_stats;            /* 1: fill the ray / traversal counters (slower kernel variant) */
-    int32_t reserved[2];
+    int32_t coop_threshold;           /* tuning: a deferred-ray list shorter than this is traced by the
+                                         cooperative (8 lanes per ray) kernels; 0 = default */
+    int32_t reserved;
     float   cam_pos[3];               /* camera.pos */
     float   origin[3];                /* CalculateImageOrigin(camera.focaldist) */
     float   u[3], v[3];               /* per-pixel steps of CalculateCurrentPoint */

@@ -61,7 +61,7 @@ class RtuSceneDesc(ctypes.Structure):
 class RtuFrameDesc(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("shard_rank", ctypes.c_int32),
                 ("shard_count", ctypes.c_int32), ("max_bounce", ctypes.c_int32), ("collect_stats", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2), ("cam_pos", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
+                ("coop_threshold", ctypes.c_int32), ("reserved", ctypes.c_int32), ("cam_pos", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
                 ("u", ctypes.c_float * 3), ("v", ctypes.c_float * 3)]
 
 

@@ -144,7 +144,7 @@ __device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t
 
 // Geometry of a stage-2 launch: rays per wavefront from the (largest shard of the) list.
 struct NarrowGeom {
-    uint32_t R, kmax, nmax;
+    uint32_t R, kmax, nmax, sum;
 };
 __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     uint32_t v = a.fcnt->n_defer[ph][lane_id() % RTU_SHARDS];
@@ -158,6 +158,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     }
     NarrowGeom g;
     g.nmax = v;
+    g.sum = sum;
     // enough wavefronts to fill 256 CUs several times over before widening them
     // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
     g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 200000) ? 64u : 8u;
@@ -240,7 +241,7 @@ template <int STACK>
 __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nodes) {
     const RTU_CONST DevMesh* meshes = as_const(a.scene.meshes);
     for (uint32_t m = 0; m < a.n_meshes; m++) {
-        const float4* src = meshes[m].bvh;
+        const float4* src = meshes[m].fast.bvh;
         const uint32_t n = meshes[m].lds_nodes * 2u, off = meshes[m].lds_off;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_nodes[off + i] = src[i];
     }
@@ -284,14 +285,18 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     stage_nodes<STACK>(a, s_nodes);
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
-    const uint32_t kmax = (g.nmax + RTU_COOP_GROUPS - 1u) / RTU_COOP_GROUPS;
+    // A very short list is pure latency: one wavefront per SIMD (32 rays per workgroup) so that
+    // the walks do not share VALU issue slots; longer lists use all 16 wavefronts.
+    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;
+    if (grp >= groups) return;
+    const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         uint32_t ns = a.fcnt->n_defer[0][shard];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * RTU_COOP_GROUPS + grp;
+        const uint32_t e = k * groups + grp;
         const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
@@ -422,14 +427,16 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
     stage_nodes<STACK>(a, s_nodes);
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
-    const uint32_t kmax = (g.nmax + RTU_COOP_GROUPS - 1u) / RTU_COOP_GROUPS;
+    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;  // see k_primary2c
+    if (grp >= groups) return;
+    const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         uint32_t ns = a.fcnt->n_defer[ph][shard];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * RTU_COOP_GROUPS + grp;
+        const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
         frame_ray<STACK, false, false, true>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);

@@ -79,6 +79,164 @@ int upload(RtuContext* ctx, const T* src, size_t count, const T** dst) {
     return RTU_OK;
 }
 
+
+// ---- binned-SAH BVH over a mesh's triangles (the `fast` tree of DevMesh) -------------------
+// Breadth-first node numbering with adjacent sibling pairs, root = node 1, node 0 unused —
+// the layout the kernels expect. Leaves hold <= 4 triangles. Box bounds are the exact
+// min/max of the vertex coordinates (no arithmetic), like cy::BVH's.
+struct SahTree {
+    std::vector<RtuBvhNode> nodes;
+    std::vector<uint32_t>   elements;
+    uint32_t depth = 0;
+};
+
+void build_sah(const RtuMesh& m, SahTree& out) {
+    const uint32_t nf = m.nf;
+    std::vector<float> bmin(3 * (size_t)nf), bmax(3 * (size_t)nf), cen(3 * (size_t)nf);
+    for (uint32_t i = 0; i < nf; i++) {
+        const uint32_t* fv = m.f + 3 * i;
+        for (int k = 0; k < 3; k++) {
+            float a = m.v[3 * fv[0] + k], b = m.v[3 * fv[1] + k], c = m.v[3 * fv[2] + k];
+            float lo = a < b ? (a < c ? a : c) : (b < c ? b : c);
+            float hi = a > b ? (a > c ? a : c) : (b > c ? b : c);
+            bmin[3 * i + k] = lo; bmax[3 * i + k] = hi; cen[3 * i + k] = 0.5f * (lo + hi);
+        }
+    }
+    std::vector<uint32_t> idx(nf);
+    for (uint32_t i = 0; i < nf; i++) idx[i] = i;
+    struct Job { uint32_t begin, end, id, level; };
+    out.nodes.assign(2, RtuBvhNode{});
+    out.elements.clear();
+    std::vector<Job> queue;
+    queue.push_back({0, nf, 1, 1});
+    auto area = [](const float* lo, const float* hi) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const Job j = queue[qi];
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f}, clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+        for (uint32_t t = j.begin; t < j.end; t++)
+            for (int k = 0; k < 3; k++) {
+                uint32_t f = idx[t];
+                if (bmin[3 * f + k] < lo[k]) lo[k] = bmin[3 * f + k];
+                if (bmax[3 * f + k] > hi[k]) hi[k] = bmax[3 * f + k];
+                if (cen[3 * f + k] < clo[k]) clo[k] = cen[3 * f + k];
+                if (cen[3 * f + k] > chi[k]) chi[k] = cen[3 * f + k];
+            }
+        if (out.nodes.size() <= j.id) out.nodes.resize(j.id + 1, RtuBvhNode{});
+        RtuBvhNode n{};
+        for (int k = 0; k < 3; k++) { n.bmin[k] = lo[k]; n.bmax[k] = hi[k]; }
+        if (j.level > out.depth) out.depth = j.level;
+        const uint32_t count = j.end - j.begin;
+        if (count <= 4) {
+            n.index = (uint32_t)out.elements.size();
+            n.count = count;
+            for (uint32_t t = j.begin; t < j.end; t++) out.elements.push_back(idx[t]);
+            out.nodes[j.id] = n;
+            continue;
+        }
+        // best binned split over the three axes
+        const int NB = 16;
+        int bestAxis = -1, bestBin = 0;
+        float bestCost = 3.0e38f;
+        for (int ax = 0; ax < 3; ax++) {
+            float ext = chi[ax] - clo[ax];
+            if (!(ext > 0)) continue;
+            uint32_t cnt[NB] = {};
+            float blo[NB][3], bhi[NB][3];
+            for (int b = 0; b < NB; b++) for (int k = 0; k < 3; k++) { blo[b][k] = 1e30f; bhi[b][k] = -1e30f; }
+            for (uint32_t t = j.begin; t < j.end; t++) {
+                uint32_t f = idx[t];
+                int b = (int)((cen[3 * f + ax] - clo[ax]) / ext * NB);
+                if (b >= NB) b = NB - 1;
+                if (b < 0) b = 0;
+                cnt[b]++;
+                for (int k = 0; k < 3; k++) {
+                    if (bmin[3 * f + k] < blo[b][k]) blo[b][k] = bmin[3 * f + k];
+                    if (bmax[3 * f + k] > bhi[b][k]) bhi[b][k] = bmax[3 * f + k];
+                }
+            }
+            // sweep: left = bins [0,s], right = (s,NB)
+            float rArea[NB];
+            uint32_t rCnt[NB];
+            {
+                float rl[3] = {1e30f, 1e30f, 1e30f}, rh[3] = {-1e30f, -1e30f, -1e30f};
+                uint32_t rc = 0;
+                for (int b = NB - 1; b > 0; b--) {
+                    for (int k = 0; k < 3; k++) { if (blo[b][k] < rl[k]) rl[k] = blo[b][k]; if (bhi[b][k] > rh[k]) rh[k] = bhi[b][k]; }
+                    rc += cnt[b];
+                    rArea[b] = rc ? area(rl, rh) : 0.0f;
+                    rCnt[b] = rc;
+                }
+            }
+            float ll[3] = {1e30f, 1e30f, 1e30f}, lh[3] = {-1e30f, -1e30f, -1e30f};
+            uint32_t lc = 0;
+            for (int sI = 0; sI < NB - 1; sI++) {
+                for (int k = 0; k < 3; k++) { if (blo[sI][k] < ll[k]) ll[k] = blo[sI][k]; if (bhi[sI][k] > lh[k]) lh[k] = bhi[sI][k]; }
+                lc += cnt[sI];
+                if (lc == 0 || rCnt[sI + 1] == 0) continue;
+                float cost = area(ll, lh) * (float)lc + rArea[sI + 1] * (float)rCnt[sI + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = sI; }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis < 0) {
+            mid = j.begin + count / 2;  // all centroids coincide: split the list in half
+        } else {
+            float ext = chi[bestAxis] - clo[bestAxis];
+            uint32_t i = j.begin, e = j.end;
+            while (i < e) {
+                uint32_t f = idx[i];
+                int b = (int)((cen[3 * f + bestAxis] - clo[bestAxis]) / ext * NB);
+                if (b >= NB) b = NB - 1;
+                if (b < 0) b = 0;
+                if (b <= bestBin) i++;
+                else { e--; uint32_t tmp = idx[i]; idx[i] = idx[e]; idx[e] = tmp; }
+            }
+            mid = i;
+            if (mid == j.begin || mid == j.end) mid = j.begin + count / 2;
+        }
+        const uint32_t child = (uint32_t)out.nodes.size() + (out.nodes.size() & 1u);  // even id: 64-byte aligned pair
+        out.nodes.resize(child + 2, RtuBvhNode{});
+        n.index = child;
+        n.count = 0;
+        out.nodes[j.id] = n;
+        queue.push_back({j.begin, mid, child, j.level + 1});
+        queue.push_back({mid, j.end, child + 1, j.level + 1});
+    }
+}
+
+// 64-byte triangle records (TriRec, rtu_intersect.h) in the order of `elements`: the
+// ray-independent part of TriObj::IntersectTriangle (objFunctions.cpp:259-300) evaluated with
+// the same float ops.
+void build_tri_records(const RtuMesh& m, const uint32_t* elements, uint32_t n, std::vector<float4>& tri) {
+    tri.resize((size_t)n * 4);
+    for (uint32_t e = 0; e < n; e++) {
+        const uint32_t* fv = m.f + 3 * elements[e];
+        f3 A = ld3(m.v + 3 * fv[0]), B = ld3(m.v + 3 * fv[1]), C = ld3(m.v + 3 * fv[2]);
+        f3 N = norm3(cross3(B - A, C - A));                                        // :263
+        float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
+        float maxNormalAxis = smax(smax(anx, any), anz);                           // :274
+        uint32_t axis = (maxNormalAxis == anx) ? 0u : (maxNormalAxis == any) ? 1u : 2u;  // :278-296
+        float ax = axis == 0 ? A.y : A.x, ay = axis == 2 ? A.y : A.z;
+        float bx = axis == 0 ? B.y : B.x, by = axis == 2 ? B.y : B.z;
+        float cx = axis == 0 ? C.y : C.x, cy = axis == 2 ? C.y : C.z;
+        float e1x = cx - ax, e1y = cy - ay, e2x = bx - ax, e2y = by - ay;
+        float TriABCArea = (float)((double)((-e1y) * e2x + e1x * e2y) / 2.0);      // :298, Point2::Cross
+        double rcp = 1.0 / (double)TriABCArea;
+        uint64_t bits;
+        memcpy(&bits, &rcp, 8);
+        uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        float flo, fhi, faxis;
+        memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4); memcpy(&faxis, &axis, 4);
+        tri[4 * e + 0] = make_float4(A.x, A.y, A.z, N.x);
+        tri[4 * e + 1] = make_float4(N.y, N.z, ax, ay);
+        tri[4 * e + 2] = make_float4(e1x, e1y, e2x, e2y);
+        tri[4 * e + 3] = make_float4(flo, fhi, faxis, 0.0f);
+    }
+}
+
 // Reject anything the kernel's indexing does not expect, so that a malformed
 // scene is an error code and never an out-of-bounds access on the GPU.
 int validate(RtuContext* ctx, const RtuSceneDesc* s) {
@@ -352,45 +510,21 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
 
     // meshes
     std::vector<DevMesh> meshes(s->n_meshes);
+    std::vector<uint32_t> fast_nodes(s->n_meshes, 0);
     uint32_t stack_needed = 1;
     for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
         const RtuMesh& m = s->meshes[mi];
         DevMesh& d = meshes[mi];
         memset(&d, 0, sizeof d);
-        // triangle records in leaf order (TriRec, rtu_intersect.h): the ray-independent part of
-        // TriObj::IntersectTriangle (objFunctions.cpp:259-300) evaluated with the same float ops
-        std::vector<float4> tri((size_t)m.n_elements * 4);
-        for (uint32_t e = 0; e < m.n_elements; e++) {
-            const uint32_t* fv = m.f + 3 * m.elements[e];
-            f3 A = ld3(m.v + 3 * fv[0]), B = ld3(m.v + 3 * fv[1]), C = ld3(m.v + 3 * fv[2]);
-            f3 N = norm3(cross3(B - A, C - A));                                        // :263
-            float anx = fabsf(N.x), any = fabsf(N.y), anz = fabsf(N.z);
-            float maxNormalAxis = smax(smax(anx, any), anz);                           // :274
-            uint32_t axis = (maxNormalAxis == anx) ? 0u : (maxNormalAxis == any) ? 1u : 2u;  // :278-296
-            float ax = axis == 0 ? A.y : A.x, ay = axis == 2 ? A.y : A.z;
-            float bx = axis == 0 ? B.y : B.x, by = axis == 2 ? B.y : B.z;
-            float cx = axis == 0 ? C.y : C.x, cy = axis == 2 ? C.y : C.z;
-            float e1x = cx - ax, e1y = cy - ay, e2x = bx - ax, e2y = by - ay;
-            float TriABCArea = (float)((double)((-e1y) * e2x + e1x * e2y) / 2.0);      // :298, Point2::Cross
-            double rcp = 1.0 / (double)TriABCArea;
-            uint64_t bits;
-            memcpy(&bits, &rcp, 8);
-            uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
-            float flo, fhi, faxis;
-            memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4); memcpy(&faxis, &axis, 4);
-            tri[4 * e + 0] = make_float4(A.x, A.y, A.z, N.x);
-            tri[4 * e + 1] = make_float4(N.y, N.z, ax, ay);
-            tri[4 * e + 2] = make_float4(e1x, e1y, e2x, e2y);
-            tri[4 * e + 3] = make_float4(flo, fhi, faxis, 0.0f);
-        }
+        std::vector<float4> tri;
+        build_tri_records(m, m.elements, m.n_elements, tri);
         for (uint32_t i = 1; i < m.n_bvh_nodes; i++) {
             const RtuBvhNode& bn = m.bvh[i];
             if (bn.bmin[0] > bn.bmax[0] || bn.bmin[1] > bn.bmax[1] || bn.bmin[2] > bn.bmax[2]) d.any_empty_box = 1;
         }
         static_assert(sizeof(RtuBvhNode) == 2 * sizeof(float4), "BVH node is two float4");
-        // Renumber the nodes breadth-first (sibling pairs stay adjacent, the root stays node 1):
-        // same tree, same traversal, but the top levels become the first entries of the
-        // array, which is what the cooperative kernels stage into LDS.
+        // `ref` tree: the reference's, renumbered breadth-first (sibling pairs stay adjacent, the
+        // root stays node 1): same tree, same traversal order.
         std::vector<RtuBvhNode> bfs(m.n_bvh_nodes);
         memset(bfs.data(), 0, bfs.size() * sizeof(RtuBvhNode));
         {
@@ -409,9 +543,19 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
                 bfs[newId] = nn;
             }
         }
-        if ((rc = upload(ctx, reinterpret_cast<const float4*>(bfs.data()), (size_t)m.n_bvh_nodes * 2, &d.bvh)) != RTU_OK) return rc;
-        if ((rc = upload(ctx, tri.data(), tri.size(), &d.tri)) != RTU_OK) return rc;
-        if ((rc = upload(ctx, m.elements, (size_t)m.n_elements, &d.elements)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, reinterpret_cast<const float4*>(bfs.data()), (size_t)m.n_bvh_nodes * 2, &d.ref.bvh)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, tri.data(), tri.size(), &d.ref.tri)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, m.elements, (size_t)m.n_elements, &d.ref.elements)) != RTU_OK) return rc;
+        // `fast` tree: binned SAH over the same triangles
+        SahTree sah;
+        build_sah(m, sah);
+        if (sah.depth > RTU_MAX_BVH_STACK) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: SAH tree depth %u > %d", mi, sah.depth, RTU_MAX_BVH_STACK);
+        build_tri_records(m, sah.elements.data(), (uint32_t)sah.elements.size(), tri);
+        if ((rc = upload(ctx, reinterpret_cast<const float4*>(sah.nodes.data()), sah.nodes.size() * 2, &d.fast.bvh)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, tri.data(), tri.size(), &d.fast.tri)) != RTU_OK) return rc;
+        if ((rc = upload(ctx, sah.elements.data(), sah.elements.size(), &d.fast.elements)) != RTU_OK) return rc;
+        fast_nodes[mi] = (uint32_t)sah.nodes.size();
+        if (sah.depth > stack_needed) stack_needed = sah.depth;
         if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.fn, (size_t)m.nf * 3, &d.fn)) != RTU_OK) return rc;
@@ -430,7 +574,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         uint32_t budget = (uint32_t)RTU_LDS_NODE_F4(stack_sel) / 2;  // nodes
         uint32_t used = 0;
         for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
-            uint32_t take = s->meshes[mi].n_bvh_nodes;
+            uint32_t take = fast_nodes[mi];
             if (take > budget - used) take = budget - used;
             take &= ~1u;  // whole sibling pairs
             meshes[mi].lds_nodes = take;

@@ -28,10 +28,23 @@ template <class T> __device__ __forceinline__ const RTU_CONST T* as_const(const 
 #pragma clang diagnostic pop
 }
 
-struct DevMesh {
-    const float4*   bvh;        // 2 float4 per RtuBvhNode: {bmin.xyz, index} {bmax.xyz, count}
+// One BVH over a mesh's triangles with its leaf-ordered triangle records.
+struct DevTree {
+    const float4*   bvh;        // 2 float4 per node: {bmin.xyz, index} {bmax.xyz, count}; root = node 1; breadth-first
     const float4*   tri;        // 4 float4 per element slot (leaf order), see TriRec in rtu_intersect.h
     const uint32_t* elements;   // element slot -> face id
+};
+
+// Two trees per mesh:
+//   ref  — the reference's own tree (cy::BVH mean split, cyBVH.h:122-328): defines the ORDER in
+//          which triangles are tested, which decides the winner when two triangles give exactly
+//          the same t (strict `t < hInfo.z`, objFunctions.cpp:270). The counting variant walks it.
+//   fast — a binned-SAH tree over the same triangles (fewer steps per ray). The closest hit is
+//          a minimum over the accepted triangles and therefore order-independent UNLESS two
+//          accepted triangles tie exactly; the fast walk detects that (rtu_intersect.h) and
+//          redoes the ray on `ref`, so the result is always the reference's.
+struct DevMesh {
+    DevTree ref, fast;
     const uint32_t* f;          // face -> 3 vertex ids
     const float*    v;
     const uint32_t* fn;

@@ -216,9 +216,9 @@ __device__ __forceinline__ f3 interp(const float* arr, const uint32_t* face, f3 
 struct TriRec {
     float4 r0, r1, r2, r3;
 };
-__device__ __forceinline__ TriRec load_tri(const RTU_CONST DevMesh& mesh, uint32_t slot) {
+__device__ __forceinline__ TriRec load_tri(const float4* tri, uint32_t slot) {
     TriRec t;
-    const float4* p = mesh.tri + 4 * (size_t)slot;
+    const float4* p = tri + 4 * (size_t)slot;
     t.r0 = p[0]; t.r1 = p[1]; t.r2 = p[2]; t.r3 = p[3];
     return t;
 }
@@ -230,15 +230,18 @@ struct TriWin {
     uint32_t slot;
     f3 bc;
 };
-template <bool STATS>
-__device__ __forceinline__ bool tri_hit(const TriRec& T, uint32_t slot, const Ray& ray, Hit& h, TriWin& win, Counters& cnt) {
+// Returns 1 when the triangle is accepted (t < h.z), 0 when not. TIE (fast tree only): returns 2
+// when the triangle passes every geometric test with t EXACTLY EQUAL to h.z — which triangle
+// wins then depends on the reference's test order, so the caller falls back to the `ref` tree.
+template <bool STATS, bool TIE>
+__device__ __forceinline__ int tri_hit(const TriRec& T, uint32_t slot, const Ray& ray, Hit& h, TriWin& win, Counters& cnt) {
     RTU_CNT(tri);
     const f3 A = mk3(T.r0.x, T.r0.y, T.r0.z);
     const f3 N = mk3(T.r0.w, T.r1.x, T.r1.y);
     const float dn = dot3(ray.dir, N);
     if (dn != 0) {
         const float t = dot3(A - ray.p, N) / dn;
-        if ((double)t > 0.00001 && t < h.z) {  // :270
+        if ((double)t > 0.00001 && (TIE ? t <= h.z : t < h.z)) {  // :270
             const f3 q = ray.p + ray.dir * t;
             const uint32_t axis = __float_as_uint(T.r3.z);
             const float qx = axis == 0 ? q.y : q.x;
@@ -252,16 +255,17 @@ __device__ __forceinline__ bool tri_hit(const TriRec& T, uint32_t slot, const Ra
             const float BC2 = fdiv(TriABPArea, rcpABC);
             const float BC3 = (float)(1.0 - (double)BC1 - (double)BC2);  // :304
             if (BC1 > 0 && BC2 > 0 && BC3 > 0 && BC1 < 1 && BC2 < 1 && BC3 < 1) {
+                if (TIE && t == h.z) return 2;
                 RTU_CNT(acc);
                 win.slot = slot;
                 win.bc = mk3(BC3, BC1, BC2);
                 h.front = dn < 0;
                 h.z = t;
-                return true;
+                return 1;
             }
         }
     }
-    return false;
+    return 0;
 }
 
 // TriObj::IntersectRay (objFunctions.cpp:333-406) — the hot loop on mesh scenes.
@@ -282,11 +286,9 @@ __device__ __forceinline__ bool tri_hit(const TriRec& T, uint32_t slot, const Ra
 //    margin that covers the rounding of the slab and triangle arithmetic (see
 //    DESIGN.md "Culling margin"): every triangle in it would fail `t < hInfo.z`
 //    (objFunctions.cpp:270), so skipping it cannot change any output bit.
-template <int STACK, bool STATS, bool CULL>
-__device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
-                                         const uint32_t stride = 64) {
-    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
-    RTU_CNT(mesh);
+template <int STACK, bool STATS, bool CULL, bool TIE>
+__device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const float4* bvh, const float4* tris, const uint32_t* elements,
+                                          const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, const uint32_t stride, bool& tie) {
     // The reference's slab test has special cases for an exactly-zero direction component
     // (objFunctions.cpp:154-216). If ANY lane of the wavefront has one, the whole wavefront
     // takes the literal four-branch form; otherwise the branch-free reciprocal form.
@@ -306,13 +308,13 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
     win.slot = 0;
     win.bc = mk3(0, 0, 0);
     int sp = 0;
-    float4 r0 = mesh.bvh[2], r1 = mesh.bvh[3];  // root = node 1 (cyBVH.h:76)
+    float4 r0 = bvh[2], r1 = bvh[3];  // root = node 1 (cyBVH.h:76)
     uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
     bool alive = true;
     while (alive) {
         while (alive && count == 0) {  // inner nodes
             RTU_CNT(inner);
-            const float4* pair = mesh.bvh + 2 * index;  // children index, index+1: one 64-byte line
+            const float4* pair = bvh + 2 * index;  // children index, index+1: one 64-byte line
             float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
             float e1, x1, e2, x2;
             f3 amin = mk3(a0.x, a0.y, a0.z), amax = mk3(a1.x, a1.y, a1.z);
@@ -365,13 +367,16 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
         if (alive) {  // leaf: :394-396; the next record is fetched while the current one is tested
             RTU_CNT(leafv);
             if (STATS) cnt.leafe += count;
-            TriRec cur = load_tri(mesh, index);
+            TriRec cur = load_tri(tris, index);
             for (uint32_t i = 0; i < count; i++) {
                 TriRec nxt = cur;
-                if (i + 1 < count) nxt = load_tri(mesh, index + i + 1);
-                hitResult |= tri_hit<STATS>(cur, index + i, ray, h, win, cnt);
+                if (i + 1 < count) nxt = load_tri(tris, index + i + 1);
+                const int code = tri_hit<STATS, TIE>(cur, index + i, ray, h, win, cnt);
+                if (TIE && code == 2 && hitResult && !shadow) tie = true;  // equal t with the current best of THIS mesh
+                hitResult |= code == 1;
                 cur = nxt;
             }
+            if (TIE && tie) alive = false;
             if (CULL && shadow && hitResult) {
                 alive = false;
             } else if (sp > 0) {
@@ -384,13 +389,32 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
             }
         }
     }
-    if (hitResult && !shadow) {
+    if (hitResult && !shadow && !(TIE && tie)) {
         // hInfo.N / hInfo.p of the winning triangle (:322, :324)
-        const uint32_t face = mesh.elements[win.slot];
+        const uint32_t face = elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
     }
     return hitResult;
+}
+
+// The counting variant walks the reference's tree; the fast variant walks the SAH tree and
+// falls back to the reference's on an exact tie (see DevMesh).
+template <int STACK, bool STATS, bool CULL>
+__device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+                                         const uint32_t stride = 64) {
+    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
+    RTU_CNT(mesh);
+    bool tie = false;
+    if (!CULL) return mesh_walk<STACK, STATS, false, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, tie);
+    const Hit h0 = h;
+    bool r = mesh_walk<STACK, STATS, CULL, true>(mesh, mesh.fast.bvh, mesh.fast.tri, mesh.fast.elements, ray, shadow, h, stk, cnt, stride, tie);
+    if (tie) {  // rare: two accepted triangles with bitwise-equal t — the reference's test order decides
+        h = h0;
+        bool t2 = false;
+        r = mesh_walk<STACK, STATS, CULL, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2);
+    }
+    return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -432,6 +456,10 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
     const bool zeroDir = ray.dir.x == 0 || ray.dir.y == 0 || ray.dir.z == 0;
     if (__any(zeroDir) || mesh.any_empty_box)  // literal special-case form: every lane of the group walks alone
         return mesh_hit<STACK, false, CULL>(mesh, ray, shadow, h, stk, cnt, stride);
+    const Hit h0 = h;
+    bool tie = false;
+    const float4* bvh = mesh.fast.bvh;
+    const float4* tris = mesh.fast.tri;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & 7u;
     // role of this lane in an inner step
@@ -453,7 +481,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
     win.slot = 0;
     win.bc = mk3(0, 0, 0);
     int sp = 0;
-    float4 r0 = mesh.bvh[2], r1 = mesh.bvh[3];  // root = node 1
+    float4 r0 = bvh[2], r1 = bvh[3];  // root = node 1
     uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
     bool alive = true;
     while (alive) {
@@ -463,7 +491,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
                 const float* pair = reinterpret_cast<const float*>(lds_nodes + mesh.lds_off + 2 * index);
                 w0 = pair[o0]; w1 = pair[o1];
             } else {
-                const float* pair = reinterpret_cast<const float*>(mesh.bvh + 2 * index);
+                const float* pair = reinterpret_cast<const float*>(bvh + 2 * index);
                 w0 = pair[o0]; w1 = pair[o1];
             }
             // lanes 0..5: one slab (objFunctions.cpp:223-240)
@@ -513,20 +541,33 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
             myWin.slot = index + sub;
             myWin.bc = mk3(0, 0, 0);
             if (sub < count) {
-                const TriRec T = load_tri(mesh, index + sub);
+                const TriRec T = load_tri(tris, index + sub);
                 Hit hl = h;  // test against the best BEFORE this leaf; the reduction below applies the order
-                if (tri_hit<false>(T, index + sub, ray, hl, myWin, cnt)) { myT = hl.z; myFront = hl.front; }
+                const int code = tri_hit<false, true>(T, index + sub, ray, hl, myWin, cnt);
+                if (code == 1) { myT = hl.z; myFront = hl.front; }
+                if (code == 2 && hitResult && !shadow) tie = true;
             }
             // min t over the group, lower sub wins a tie: key = (t, sub)
             int kt = __float_as_int(myT), ks = (int)sub;  // accepted t is positive: integer order == float order
             {
+                const int big = __float_as_int(RTU_BIGFLOAT);
                 int ot = grp_xor<1>(kt), os = grp_xor<1>(ks);
+                if (ot == kt && kt != big && !shadow) tie = true;  // two triangles of this leaf accepted with equal t
                 if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
                 ot = grp_xor<2>(kt); os = grp_xor<2>(ks);
+                if (ot == kt && kt != big && os != ks && !shadow) tie = true;
                 if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
                 ot = grp_xor<4>(kt); os = grp_xor<4>(ks);
+                if (ot == kt && kt != big && os != ks && !shadow) tie = true;
                 if (ot < kt || (ot == kt && os < ks)) { kt = ot; ks = os; }
             }
+            // any lane of the group saw a tie -> the whole group falls back (keeps the lanes in lockstep)
+            {
+                int tf = tie ? 1 : 0;
+                tf |= grp_xor<1>(tf); tf |= grp_xor<2>(tf); tf |= grp_xor<4>(tf);
+                tie = tf != 0;
+            }
+            if (tie) alive = false;
             const float bestT = __int_as_float(kt);
             if (bestT < h.z) {  // somebody accepted a triangle (accepted t < h.z, misses carry BIGFLOAT >= h.z)
                 const int src = (int)(((lane & ~7u) + (uint32_t)ks) << 2);
@@ -550,8 +591,13 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
             }
         }
     }
+    if (tie) {  // redo this ray on the reference's tree, one lane per ray (all eight lanes identically)
+        h = h0;
+        bool t2 = false;
+        return mesh_walk<STACK, false, CULL, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2);
+    }
     if (hitResult && !shadow) {
-        const uint32_t face = mesh.elements[win.slot];
+        const uint32_t face = mesh.fast.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
     }

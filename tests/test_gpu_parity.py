@@ -157,6 +157,48 @@ def test_begin_render_dropin(pkg, orc, golden, tmp_path):
     assert np.abs(rgb.astype(np.int32) - g.npz["result_u8"].astype(np.int32)).max() <= RGB8_TOL
 
 
+def test_exact_ties_follow_the_reference_order(pkg, orc, ctx, tmp_path):
+    """Two coincident triangles give bitwise-equal t; the reference keeps whichever its BVH
+    walk tests first (strict `t < hInfo.z`). The fast path walks a different (SAH) tree, must
+    notice the tie and redo the ray in the reference's order: duplicated geometry with
+    DIFFERENT vertex normals makes a wrong winner visible in the colour."""
+    import random
+    rnd = random.Random(7)
+    verts, norms, faces = [], [], []
+    def add_tri(a, b, c, n):
+        base = len(verts)
+        verts.extend([a, b, c])
+        norms.extend([n, n, n])
+        faces.append((base + 1, base + 2, base + 3))
+    for i in range(40):  # 40 triangles, each present twice with different shading normals
+        cx, cy = rnd.uniform(-4, 4), rnd.uniform(-4, 4)
+        a, b, c = (cx, cy, 0.1 * i), (cx + 1.5, cy, 0.1 * i), (cx, cy + 1.5, 0.1 * i)
+        add_tri(a, b, c, (0, 0, 1))
+        add_tri(a, b, c, (0.6, 0, 0.8))
+    obj = tmp_path / "dup.obj"
+    with open(obj, "w") as f:
+        for v in verts: f.write("v %r %r %r\n" % v)
+        for n in norms: f.write("vn %r %r %r\n" % n)
+        for (i, j, k) in faces: f.write("f %d//%d %d//%d %d//%d\n" % (i, i, j, j, k, k))
+    xml = tmp_path / "dup.xml"
+    xml.write_text("""<xml><scene>
+      <object type="obj" name="%s" material="m"/>
+      <material type="blinn" name="m"><diffuse r="0.8" g="0.5" b="0.2"/><specular value="0.5"/></material>
+      <light type="direct" name="d"><intensity value="1"/><direction x="-0.3" y="0.2" z="-1"/></light>
+      <light type="ambient" name="a"><intensity value="0.1"/></light>
+    </scene><camera><position x="0" y="0" z="20"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="40"/>
+      <width value="160"/><height value="120"/></camera></xml>""" % obj)
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 160, 120
+    fast, _ = render_gpu(pkg, ctx, scene, W, H, stats=False)
+    cnt, gst = render_gpu(pkg, ctx, scene, W, H, stats=True)
+    cpu, cst = orc.render(scene, W, H, threads=2)
+    assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "tie resolved differently from the reference order"
+    check_against(fast, cpu, orc)
+    assert gst == cst
+    assert gst["primary_hits"] > 1000
+
+
 def test_exact_division(pkg, ctx):
     """(float)((double)n * (1.0/(double)d)) == n / d bit for bit (rtu_intersect.h fdiv): 2^31
     pseudo-random operand pairs incl. subnormals, zeros, infinities, NaNs, near-1 quotients."""

@@ -282,15 +282,16 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
     const NarrowGeom g = narrow_geom(a, 0);
     if (g.R != 8u) return;
-    stage_nodes<STACK>(a, s_nodes);
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
     // A very short list is pure latency: one wavefront per SIMD (32 rays per workgroup) so that
     // the walks do not share VALU issue slots; longer lists use all 16 wavefronts.
     const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;
-    if (grp >= groups) return;
     const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
+    if (blockIdx.x >= chunks) return;  // nothing for this workgroup: do not stage the tree
+    stage_nodes<STACK>(a, s_nodes);
+    if (grp >= groups) return;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
@@ -424,13 +425,14 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
     __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
     const NarrowGeom g = narrow_geom(a, ph);
     if (g.R != 8u) return;
-    stage_nodes<STACK>(a, s_nodes);
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
     const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;  // see k_primary2c
-    if (grp >= groups) return;
     const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
+    if (blockIdx.x >= chunks) return;
+    stage_nodes<STACK>(a, s_nodes);
+    if (grp >= groups) return;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;

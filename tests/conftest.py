@@ -13,6 +13,9 @@ REFERENCE = "/root/reference"  # exists only in the authoring container, never o
 
 SMALL_TAGS = ["p1_256", "p4_240x135", "teapot2_240x135", "p11_240x135"]
 FULL_TAGS = ["p3s_800x600", "p4_1080", "teapot2_1080", "p11_1080"]
+EXTRA_TAGS = ["p1test_200x150", "p2_200x150", "p3box_200x150", "p5_200x150", "p5low_200x150", "p11simple_200x150",
+              "p13_200x150"]  # the reference's other deterministic scenes
+SMALL_TAGS = SMALL_TAGS + EXTRA_TAGS
 ALL_TAGS = SMALL_TAGS + FULL_TAGS
 
 

@@ -35,6 +35,14 @@ CONFIGS = [
     ("p4_240x135", "Project4.xml", 240, 135, True),
     ("teapot2_240x135", "Teapot/scene2.xml", 240, 135, True),
     ("p11_240x135", "Project11/scene.xml", 240, 135, True),
+    # the reference's other deterministic, untextured scenes, as extra regression inputs
+    ("p1test_200x150", "Project1Test.xml", 200, 150, True),
+    ("p2_200x150", "Project2.xml", 200, 150, True),
+    ("p3box_200x150", "Project3Box.xml", 200, 150, True),
+    ("p5_200x150", "Project5/scene.xml", 200, 150, True),
+    ("p5low_200x150", "Project5/scene-low.xml", 200, 150, True),
+    ("p11simple_200x150", "Project11/scene_simple.xml", 200, 150, True),
+    ("p13_200x150", "Project13/scene.xml", 200, 150, True),
 ]
 
 
@@ -43,7 +51,10 @@ def sha(a):
 
 
 def main():
+    only = set(sys.argv[1:])
     for tag, scene, W, H, full in CONFIGS:
+        if only and tag not in only:
+            continue
         subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"])
         src = os.path.join(REPO, "oracle", "_ref", "out", tag)
         dst = os.path.join(HERE, tag)

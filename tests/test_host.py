@@ -16,6 +16,9 @@ SCENES = {
     "p1_256": "Project1Example.xml", "p3s_800x600": "Project3Simple.xml", "p4_1080": "Project4.xml",
     "teapot2_1080": "Teapot/scene2.xml", "p11_1080": "Project11/scene.xml", "p4_240x135": "Project4.xml",
     "teapot2_240x135": "Teapot/scene2.xml", "p11_240x135": "Project11/scene.xml",
+    "p1test_200x150": "Project1Test.xml", "p2_200x150": "Project2.xml", "p3box_200x150": "Project3Box.xml",
+    "p5_200x150": "Project5/scene.xml", "p5low_200x150": "Project5/scene-low.xml",
+    "p11simple_200x150": "Project11/scene_simple.xml", "p13_200x150": "Project13/scene.xml",
 }
 
 

@@ -54,7 +54,7 @@ struct DevMesh {
     uint32_t any_empty_box;     // some BVH box has min > max (cannot come from triangles)
     uint32_t lds_nodes;         // nodes [0, lds_nodes) are staged in LDS by the cooperative kernels (BFS order: the top of the tree)
     uint32_t lds_off;           // their offset in the block's LDS node area, in float4
-    uint32_t pad;
+    float    scale;             // largest |coordinate| of the mesh's bounding box (cull margin, rtu_intersect.h)
 };
 
 struct DevNode {                // one scene-graph node (wave-uniform data)

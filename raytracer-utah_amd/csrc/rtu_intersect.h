@@ -108,8 +108,37 @@ __device__ __forceinline__ RayRcp ray_rcp(const Ray& r) {
     c.rz = 1.0 / (double)r.dir.z;
     return c;
 }
+// ---- culling (fast variant only) -----------------------------------------------------------
+// A BVH child is skipped when, on SOME axis k, the box is geometrically separated from the
+// part of the ray that can still produce an accepted hit by more than delta = 1e-4 * scale
+// (scale = largest coordinate magnitude of the mesh and the ray origin):
+//   near side: the ray reaches the box's k-slab only after t = h.z      (entry_k - h.z) * |dir_k| > delta
+//   behind   : the box's k-slab ends before the ray origin              (0 - exit_k)    * |dir_k| > delta
+// Why this cannot change a result: the reference accepts a triangle only with 0.00001 < t < h.z
+// and its hit point q = p + dir*t projected inside the triangle on two axes (objFunctions.cpp:270-306).
+// With the separation on a projected axis, q lies outside the box (hence outside the triangle) by
+// delta >> the rounding of q (~2e-7*scale). With the separation on the axis of the dominant
+// normal component (|N_k| >= 0.577), the plane residual |dn*t - N.(A-p)| at that t would have to
+// exceed 0.577*delta, while for the COMPUTED t it is bounded by the rounding of the two dot
+// products and the division, ~1.5e-6*scale. delta leaves a 40x reserve. (An axis with
+// dir_k == 0 never culls: lim_k = inf.) The reference itself walks such boxes (its box test has no
+// `tExit >= 0` and no comparison with h.z) and rejects their triangles.
+struct CullLim {
+    float lx, ly, lz;  // delta / |dir_k|
+};
+__device__ __forceinline__ CullLim cull_limits(const Ray& r, float scale) {
+    const float delta = 1e-4f * scale;
+    CullLim c;
+    c.lx = delta / fabsf(r.dir.x);
+    c.ly = delta / fabsf(r.dir.y);
+    c.lz = delta / fabsf(r.dir.z);
+    return c;
+}
 // General case of the slab test (no exactly-zero direction component), objFunctions.cpp:223-245.
-__device__ __forceinline__ void box_slabs_rcp(const Ray& r, const RayRcp& c, f3 bmin, f3 bmax, float& tEntry, float& tExit) {
+// `skip` (CULL only): the box cannot contain an acceptable triangle, see above.
+template <bool CULL>
+__device__ __forceinline__ void box_slabs_rcp(const Ray& r, const RayRcp& c, f3 bmin, f3 bmax, float hz, const CullLim& L,
+                                              float& tEntry, float& tExit, bool& skip) {
     float tx0 = fdiv(bmin.x - r.p.x, c.rx), tx1 = fdiv(bmax.x - r.p.x, c.rx);
     float ty0 = fdiv(bmin.y - r.p.y, c.ry), ty1 = fdiv(bmax.y - r.p.y, c.ry);
     float tz0 = fdiv(bmin.z - r.p.z, c.rz), tz1 = fdiv(bmax.z - r.p.z, c.rz);
@@ -119,6 +148,9 @@ __device__ __forceinline__ void box_slabs_rcp(const Ray& r, const RayRcp& c, f3 
     float az0 = sz ? tz1 : tz0, az1 = sz ? tz0 : tz1;
     tEntry = smax(smax(ax0, ay0), az0);
     tExit = smin(smin(ax1, ay1), az1);
+    skip = false;
+    if (CULL)
+        skip = (ax0 - L.lx > hz) || (ay0 - L.ly > hz) || (az0 - L.lz > hz) || (ax1 < -L.lx) || (ay1 < -L.ly) || (az1 < -L.lz);
 }
 
 __device__ __forceinline__ bool box_empty(f3 bmin, f3 bmax) {  // Box::IsEmpty, scene.h:85
@@ -296,13 +328,10 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
     const bool slowSlabs = __any(zeroDir) != 0;
     const RayRcp rc = ray_rcp(ray);
     const bool emptyBoxes = mesh.any_empty_box != 0;  // never for a BVH built from triangles; uniform
-    // margin of the h.z cull, relative: 1e-3 + 8e-6 / (smallest normalised |dir| component)
-    float cullK = 0.0f;
-    if (CULL) {
-        float ax = fabsf(ray.dir.x), ay = fabsf(ray.dir.y), az = fabsf(ray.dir.z);
-        float mn = fminf(ax, fminf(ay, az));
-        cullK = 1.0f + 1e-3f + 8e-6f * (len3(ray.dir) / mn);  // +inf for an axis-parallel ray: never cull
-    }
+    CullLim lim;
+    lim.lx = lim.ly = lim.lz = 0.0f;
+    if (CULL) lim = cull_limits(ray, mesh.scale > fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z))) ? mesh.scale
+                                    : fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z))));
     bool hitResult = false;
     TriWin win;
     win.slot = 0;
@@ -319,12 +348,13 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
             float e1, x1, e2, x2;
             f3 amin = mk3(a0.x, a0.y, a0.z), amax = mk3(a1.x, a1.y, a1.z);
             f3 bmin = mk3(b0.x, b0.y, b0.z), bmax = mk3(b1.x, b1.y, b1.z);
-            if (slowSlabs) {
+            bool skip1 = false, skip2 = false;
+            if (slowSlabs) {  // literal form, no culling
                 box_slabs(ray, amin, amax, e1, x1);
                 box_slabs(ray, bmin, bmax, e2, x2);
             } else {
-                box_slabs_rcp(ray, rc, amin, amax, e1, x1);
-                box_slabs_rcp(ray, rc, bmin, bmax, e2, x2);
+                box_slabs_rcp<CULL>(ray, rc, amin, amax, h.z, lim, e1, x1, skip1);
+                box_slabs_rcp<CULL>(ray, rc, bmin, bmax, h.z, lim, e2, x2, skip2);
             }
             // BVHBoxIntersection (:408-522): -t_max for an empty box, tEntry + 0.01 (fp64) on a hit, else t_max
             float t1 = (e1 <= x1 && e1 < RTU_BIGFLOAT) ? (float)((double)e1 + 0.01) : RTU_BIGFLOAT;
@@ -335,9 +365,8 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
             }
             bool v1 = t1 != RTU_BIGFLOAT, v2 = t2 != RTU_BIGFLOAT;
             if (CULL) {
-                float lim = h.z * cullK + 1e-4f;
-                v1 = v1 && !(e1 > lim);
-                v2 = v2 && !(e2 > lim);
+                v1 = v1 && !skip1;
+                v2 = v2 && !skip2;
             }
             // :361-389: (t1 <= t2) push c2 then c1; else push c1 then c2
             bool firstIsC1 = t1 <= t2;
@@ -470,11 +499,11 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
     const float p_a = axis == 0 ? ray.p.x : axis == 1 ? ray.p.y : ray.p.z;
     const float d_a = axis == 0 ? ray.dir.x : axis == 1 ? ray.dir.y : ray.dir.z;
     const double rcp_a = 1.0 / (double)d_a;
-    float cullK = 0.0f;
+    // this lane's share of the cull test (see cull_limits): its own axis
+    float lim_a = 0.0f;
     if (CULL) {
-        float ax = fabsf(ray.dir.x), ay = fabsf(ray.dir.y), az = fabsf(ray.dir.z);
-        float mn = fminf(ax, fminf(ay, az));
-        cullK = 1.0f + 1e-3f + 8e-6f * (len3(ray.dir) / mn);
+        const float pm = fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z)));
+        lim_a = 1e-4f * (mesh.scale > pm ? mesh.scale : pm) / fabsf(d_a);
     }
     bool hitResult = false;
     TriWin win;
@@ -506,7 +535,12 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
             const float e = smax(smax(a0, y0), z0), x = smin(smin(a1, y1), z1);
             float t = (e <= x && e < RTU_BIGFLOAT) ? (float)((double)e + 0.01) : RTU_BIGFLOAT;  // :516-521
             bool v = t != RTU_BIGFLOAT;
-            if (CULL) v = v && !(e > h.z * cullK + 1e-4f);
+            if (CULL) {  // lanes 0..5 test their own axis; lanes 0 and 3 gather the verdicts of their child
+                const float mySkip = ((a0 - lim_a > h.z) || (a1 < -lim_a)) ? 1.0f : 0.0f;
+                const float s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mySkip), 0x101, 0xF, 0xF, true));
+                const float s2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mySkip), 0x102, 0xF, 0xF, true));
+                v = v && mySkip == 0.0f && s1 == 0.0f && s2 == 0.0f;
+            }
             const float pk = __uint_as_float(__float_as_uint(w0) | (__float_as_uint(w1) << 28));  // lanes 6,7
             // every lane fetches both children's verdicts and decides identically
             const float tA = grp_bcast(t, 0), tB = grp_bcast(t, 3);

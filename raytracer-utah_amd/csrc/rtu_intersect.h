@@ -169,11 +169,15 @@ __device__ __forceinline__ bool box_hit(const Ray& r, f3 bmin, f3 bmax, float t_
 // fall-through of the n<m branch. uvw is not produced (no
 // textures on this path).
 __device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
-    if (!box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     float a = dot3(ray.dir, ray.dir);
     float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
     float c = dot3(ray.p, ray.p) - 1;
     float sqrtCheck = b * b - 4 * a * c;
+    // The reference tests the unit bounding box first (:17) and then the quadratic. Both are
+    // pure, so the order is free: with a negative (or NaN) discriminant m and n are NaN and
+    // every branch of :29-:99 is false whatever the box test says — skip its six divisions.
+    if (!(sqrtCheck >= 0)) return false;
+    if (!box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     float sq = sqrtf(sqrtCheck);
     float m = (-b + sq) / (2 * a);
     float n = (-b - sq) / (2 * a);
@@ -212,12 +216,14 @@ __device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
 
 // Plane::IntersectRay (objFunctions.cpp:107-140)
 __device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) {
-    if (!box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
+    // As in sphere_hit the bounding-box test (:109) is evaluated last: it only matters for a
+    // ray that passes every other condition of :110-:118.
     if (ray.dir.z != 0) {
         float t = (-ray.p.z) / (ray.dir.z);
         if ((double)t > 0.001 && t < h.z) {
             f3 q = ray.p + ray.dir * t;
             if (q.x > -1 && q.x < 1 && q.y > -1 && q.y < 1) {
+                if (!box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
                 h.front = ray.p.z > 0;
                 h.N = mk3(0, 0, h.front ? 1.0f : -1.0f);
                 h.z = t;

@@ -122,6 +122,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # HIP events on the launch stream
+    ctx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
 
     t = torch.tensor([elapsed, kernel_ms, float(alg_bytes_launch)], dtype=torch.float64, device=dev)
     if dist:

@@ -113,6 +113,15 @@ int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz,
  * frame again). rtu_render_frame does this check and the re-render itself. */
 int  rtu_frame_status(RtuContext* ctx);
 
+/* Diagnostic: render one frame with every wavefront stamping the GPU's constant clock on entry
+ * and exit, and return, per kernel launch that ran, its slot (0 primary, 1/2 primary stage 2
+ * cooperative/wide, 3+4L.. trace, stage 2 cooperative, stage 2 wide, consume of level L,
+ * 27+L combine of level L) and the first-entry / last-exit times in microseconds from the first
+ * stamp. Unlike a profiler trace this neither serialises nor pads the launches. Returns the
+ * number of entries (<= max_entries) or a negative RTU_ERR_*. Synchronous. */
+int  rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, int max_entries, int* slot_out,
+                         double* start_us_out, double* end_us_out);
+
 /* Counters of the last frame rendered with collect_stats=1 (synchronises). */
 int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
 

@@ -113,7 +113,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -128,6 +128,8 @@ _sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
 _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
+_sig(hip, "rtu_render_timeline", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double),
+     ctypes.POINTER(ctypes.c_double))
 _sig(hip, "rtu_get_stats", _I, _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_time_render", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P, _I, ctypes.POINTER(ctypes.c_float))
 _sig(hip, "rtu_selftest_division", _I, _P, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong))
@@ -276,6 +278,22 @@ class Context:
     def frame_status(self):
         """Synchronise; raises RtuError(RTU_ERR_CAPACITY) if the frame must be rendered again."""
         self._check(hip.rtu_frame_status(self._h))
+
+    TIMELINE_SLOTS = (["k_primary", "k_primary2c", "k_primary2"] +
+                      ["%s(L%d)" % (k, L) for L in range(6) for k in ("k_trace", "k_trace2c", "k_trace2", "k_consume")] +
+                      ["k_combine(L%d)" % L for L in range(6)])
+
+    def render_timeline(self, frame, d_ptr):
+        """One frame with in-kernel GPU-clock stamps: [(kernel, start_us, end_us)] in launch order."""
+        n = 40
+        slot, t0, t1 = (_I * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        rc = hip.rtu_render_timeline(self._h, ctypes.byref(frame), d_ptr, n, slot, t0, t1)
+        if rc < 0:
+            self._check(rc)
+        order = {name: i for i, name in enumerate(self.TIMELINE_SLOTS)}
+        rows = [(self.TIMELINE_SLOTS[slot[i]], t0[i], t1[i]) for i in range(rc)]
+        # launch order: combines run bottom-up after everything else
+        return sorted(rows, key=lambda r: (r[0].startswith("k_combine"), -order[r[0]] if r[0].startswith("k_combine") else order[r[0]]))
 
     def time_render(self, frame, d_ptr, stream, iters):
         ms = ctypes.c_float(0)

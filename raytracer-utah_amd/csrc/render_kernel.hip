@@ -45,6 +45,25 @@ enum { SEL_SHADOW = 1, SEL_MAIN = 2, SEL_A = 4, SEL_C = 8, SEL_A_NEEDS_B = 16 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// GPU-clock timeline (rtu_render_timeline): when a.tl is set the first 64 workgroups store the
+// constant 100 MHz clock on entry and every wavefront stores it on exit (plain stores into
+// per-workgroup slots, no atomics); the host takes min / max per kernel. Unlike a profiler's
+// trace this does not serialise or pad the launches. kid: RTU_TL_* slot of the launch.
+struct Stamp {
+    unsigned long long* p;
+    __device__ __forceinline__ Stamp(const KernelArgs& a, int kid) : p(nullptr) {
+        if (a.tl) {
+            p = a.tl + (size_t)kid * RTU_TL_STRIDE;
+            if (blockIdx.x < 64u && threadIdx.x == 0) p[blockIdx.x] = (unsigned long long)wall_clock64();
+        }
+    }
+    __device__ __forceinline__ ~Stamp() {
+        if (p && lane_id() == 0) p[64u + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RTU_TL_ENDS - 1u))] = (unsigned long long)wall_clock64();
+    }
+};
+enum { RTU_TL_PRIMARY = 0, RTU_TL_PRIMARY2C = 1, RTU_TL_PRIMARY2 = 2, RTU_TL_LEVEL0 = 3 /* +4L: trace, trace2c, trace2, consume */,
+       RTU_TL_COMBINE0 = 3 + 4 * RTU_MAX_LEVELS };
+
 // Wave-aggregated append: every lane with `want` gets a unique index into the level's
 // frame arrays; one atomic per wavefront. Must be reached by all 64 lanes.
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
@@ -216,6 +235,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
 template <int STACK, bool STATS>
 __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
+    const Stamp stamp(a, RTU_TL_PRIMARY);
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
     uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
     const uint32_t lane = threadIdx.x & 63u;
@@ -251,6 +271,7 @@ __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nod
 // stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
 template <int STACK>
 __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
+    const Stamp stamp(a, RTU_TL_PRIMARY2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, 0);
@@ -278,6 +299,7 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
 // (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
 template <int STACK>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
+    const Stamp stamp(a, RTU_TL_PRIMARY2C);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
     __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
     const NarrowGeom g = narrow_geom(a, 0);
@@ -375,6 +397,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
 // stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
 template <int STACK, bool STATS>
 __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
@@ -400,6 +423,7 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
 // stage 2, long lists: one lane per deferred ray
 template <int STACK>
 __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, ph);
@@ -421,6 +445,7 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
 template <int STACK>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
     __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
     const NarrowGeom g = narrow_geom(a, ph);
@@ -482,6 +507,7 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
 
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const bool haveNext = L + 1 < RTU_MAX_LEVELS;
@@ -598,6 +624,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
 
 // Frames that waited for children: combine bottom-up.
 __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
+    const Stamp stamp(a, RTU_TL_COMBINE0 + L);
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
@@ -676,8 +703,10 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         hipLaunchKernelGGL((k_primary<STACK, true>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         hipLaunchKernelGGL((k_primary<STACK, false>), gridP, dim3(256), 0, stream, a, n_tiles);
-        hipLaunchKernelGGL((k_primary2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
-        hipLaunchKernelGGL((k_primary2<STACK>), gridN, block, 0, stream, a);
+        if (a.n_meshes) {  // without meshes nothing is ever deferred
+            hipLaunchKernelGGL((k_primary2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
+            hipLaunchKernelGGL((k_primary2<STACK>), gridN, block, 0, stream, a);
+        }
     }
     for (int L = 0; L < levels; L++) {
         const int ph = 1 + L;  // defer list of this level's tracing phase
@@ -688,8 +717,10 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         } else {
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
             hipLaunchKernelGGL((k_trace<STACK, false>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
-            hipLaunchKernelGGL((k_trace2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
-            hipLaunchKernelGGL((k_trace2<STACK>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
+            if (a.n_meshes) {
+                hipLaunchKernelGGL((k_trace2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
+                hipLaunchKernelGGL((k_trace2<STACK>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
+            }
             hipLaunchKernelGGL((k_consume<false>), gridF, block, 0, stream, a, L);
         }
     }

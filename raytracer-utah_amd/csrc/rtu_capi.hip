@@ -40,6 +40,8 @@ struct RtuContext {
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
     unsigned long long* counters = nullptr;  // 11 x u64
+    unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
+    bool stamp_next = false;
 };
 
 namespace {
@@ -398,6 +400,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.out = d_out;
     memcpy(a.lv, ctx->lv, sizeof a.lv);
     a.fcnt = ctx->fcnt;
+    a.tl = ctx->stamp_next ? ctx->tl : nullptr;
     a.defer_list = ctx->defer_list;
     a.defer_cap_s = ctx->defer_cap_s;
     a.counters = stats ? ctx->counters : nullptr;
@@ -473,6 +476,7 @@ void rtu_destroy_context(RtuContext* ctx) {
     free_scene(ctx);
     free_levels(ctx);
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
+    if (ctx->tl) (void)hipFree(ctx->tl);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -751,6 +755,46 @@ int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, vo
     RTU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms_out = ms / (float)iters;
     return RTU_OK;
+}
+
+int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, int max_entries, int* slot_out, double* start_us_out,
+                        double* end_us_out) {
+    if (!ctx || !slot_out || !start_us_out || !end_us_out || max_entries < 1) return RTU_ERR_ARG;
+    int rc = check_frame(ctx, frame);
+    if (rc != RTU_OK) return rc;
+    if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
+    if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)RTU_TL_KERNELS * RTU_TL_STRIDE;
+    if (!ctx->tl) RTU_HIP(ctx, hipMalloc((void**)&ctx->tl, n * sizeof(unsigned long long)));
+    RTU_HIP(ctx, hipMemsetAsync(ctx->tl, 0, n * sizeof(unsigned long long), ctx->stream));
+    ctx->stamp_next = true;
+    rc = launch(ctx, frame, (float4*)d_rgbz, ctx->stream, true);
+    ctx->stamp_next = false;
+    if (rc != RTU_OK) return rc;
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(n);
+    RTU_HIP(ctx, hipMemcpy(h.data(), ctx->tl, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int khz = 0;
+    RTU_HIP(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (khz <= 0) khz = 100000;
+    unsigned long long lo[RTU_TL_KERNELS], hi[RTU_TL_KERNELS], t0 = ~0ull;
+    for (int k = 0; k < RTU_TL_KERNELS; k++) {
+        lo[k] = ~0ull; hi[k] = 0;
+        const unsigned long long* row = h.data() + (size_t)k * RTU_TL_STRIDE;
+        for (uint32_t j = 0; j < 64; j++) if (row[j] && row[j] < lo[k]) lo[k] = row[j];
+        for (uint32_t j = 64; j < RTU_TL_STRIDE; j++) if (row[j] > hi[k]) hi[k] = row[j];
+        if (hi[k] && lo[k] < t0) t0 = lo[k];
+    }
+    int cnt = 0;
+    for (int k = 0; k < RTU_TL_KERNELS && cnt < max_entries; k++) {
+        if (hi[k] == 0 || lo[k] == ~0ull) continue;  // not launched
+        slot_out[cnt] = k;
+        start_us_out[cnt] = (double)(lo[k] - t0) * 1e3 / (double)khz;
+        end_us_out[cnt] = (double)(hi[k] - t0) * 1e3 / (double)khz;
+        cnt++;
+    }
+    return cnt;
 }
 
 int rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches_out) {

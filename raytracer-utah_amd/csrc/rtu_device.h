@@ -122,6 +122,9 @@ struct LevelBuffers {
 #define RTU_LDS_NODE_F4(STACK) ((RTU_LDS_BYTES - RTU_COOP_GROUPS * (STACK) * 4) / 16)
 
 #define RTU_SHARDS 64
+#define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_kernel.hip)
+#define RTU_TL_ENDS 8192u   // exit-stamp slots per kernel (wavefront index modulo; a later wavefront overwrites an earlier one)
+#define RTU_TL_STRIDE (64u + RTU_TL_ENDS)
 
 struct FrameCounters {
     uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS];
@@ -135,6 +138,7 @@ struct KernelArgs {
     RtuFrameDesc frame;
     float4*      out;               // shard rows * width
     LevelBuffers lv[RTU_MAX_LEVELS];
+    unsigned long long* tl;         // GPU-clock timeline stamps (rtu_render_timeline) or nullptr
     FrameCounters* fcnt;
     uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
     uint32_t     defer_cap_s;

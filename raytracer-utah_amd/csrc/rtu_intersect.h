@@ -433,6 +433,128 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
     return hitResult;
 }
 
+// ---- the fast tree's box test ---------------------------------------------------------------
+// The SAH tree is ours, not the reference's: its box tests decide only WHICH triangles get the
+// reference's exact triangle test, never a result bit. So they need not reproduce the reference's
+// slab arithmetic — they only have to be CONSERVATIVE: never reject a box that holds a triangle
+// the reference would accept. Each box is inflated by delta = 1e-4*scale on every axis (the
+// culling margin derived above; the rounding of the test itself, ~2.4e-7*scale, is 0.24 % of it)
+// and tested with one fma per slab plane:
+//     t_near_k = near_k * r_k + (-p_k*r_k - L_k)      t_far_k = far_k * r_k + (-p_k*r_k + L_k)
+// with r_k = 1/dir_k, L_k = delta*|r_k|, near/far chosen by the sign of r_k. A box is visited iff
+// max_k t_near_k <= min_k t_far_k (the inflated box is hit), <= h.z (not beyond the best hit) and
+// min_k t_far_k >= 0 (not behind the origin) — the same three conditions as box_slabs_rcp<CULL>,
+// an inner step is ~55 instructions instead of ~130. A zero direction component is replaced by
+// +-2^-100: the slab then constrains nothing when the origin is inside it (by more than delta)
+// and rejects everything when it is outside, which is what delta-conservative means there.
+struct FastRay {
+    f3 r, cn, cf;
+    bool px, py, pz;  // r_k >= 0: the near plane is bmin_k
+};
+__device__ __forceinline__ FastRay fast_ray(const Ray& ray, float meshScale) {
+    const float tiny = 0x1p-100f;
+    const float pm = fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z)));
+    const float delta = 1e-4f * (meshScale > pm ? meshScale : pm);
+    const float dx = fabsf(ray.dir.x) < tiny ? copysignf(tiny, ray.dir.x) : ray.dir.x;
+    const float dy = fabsf(ray.dir.y) < tiny ? copysignf(tiny, ray.dir.y) : ray.dir.y;
+    const float dz = fabsf(ray.dir.z) < tiny ? copysignf(tiny, ray.dir.z) : ray.dir.z;
+    FastRay f;
+    f.r = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    const f3 pr = mk3(ray.p.x * f.r.x, ray.p.y * f.r.y, ray.p.z * f.r.z);
+    const f3 L = mk3(delta * fabsf(f.r.x), delta * fabsf(f.r.y), delta * fabsf(f.r.z));
+    f.cn = mk3(-pr.x - L.x, -pr.y - L.y, -pr.z - L.z);
+    f.cf = mk3(-pr.x + L.x, -pr.y + L.y, -pr.z + L.z);
+    f.px = f.r.x >= 0; f.py = f.r.y >= 0; f.pz = f.r.z >= 0;
+    return f;
+}
+__device__ __forceinline__ bool fast_box(const FastRay& f, float4 lo, float4 hi, float hz, float& tn) {
+    const float nx = f.px ? lo.x : hi.x, fx = f.px ? hi.x : lo.x;
+    const float ny = f.py ? lo.y : hi.y, fy = f.py ? hi.y : lo.y;
+    const float nz = f.pz ? lo.z : hi.z, fz = f.pz ? hi.z : lo.z;
+    tn = fmaxf(fmaxf(fmaf(nx, f.r.x, f.cn.x), fmaf(ny, f.r.y, f.cn.y)), fmaf(nz, f.r.z, f.cn.z));
+    const float tf = fminf(fminf(fmaf(fx, f.r.x, f.cf.x), fmaf(fy, f.r.y, f.cf.y)), fmaf(fz, f.r.z, f.cf.z));
+    return tn <= tf && tn <= hz && tf >= 0.0f;
+}
+
+// The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
+// the order only affects speed: an exact tie between two accepted triangles, the one case where
+// the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
+template <int STACK>
+__device__ __forceinline__ bool mesh_walk_fast(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+                                               const uint32_t stride, bool& tie) {
+    const float4* bvh = mesh.fast.bvh;
+    const float4* tris = mesh.fast.tri;
+    const FastRay fr = fast_ray(ray, mesh.scale);
+    bool hitResult = false;
+    TriWin win;
+    win.slot = 0;
+    win.bc = mk3(0, 0, 0);
+    int sp = 0;
+    float4 r0 = bvh[2], r1 = bvh[3];  // root = node 1 (cyBVH.h:76)
+    uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
+    bool alive = true;
+    while (alive) {
+        while (alive && count == 0) {  // inner nodes
+            const float4* pair = bvh + 2 * index;  // children index, index+1: one 64-byte line
+            const float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
+            float t1, t2;
+            const bool v1 = fast_box(fr, a0, a1, h.z, t1);
+            const bool v2 = fast_box(fr, b0, b1, h.z, t2);
+            const bool firstIsC1 = t1 <= t2;
+            const uint32_t p1 = __float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28);
+            const uint32_t p2 = __float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28);
+            const uint32_t nearP = firstIsC1 ? p1 : p2, farP = firstIsC1 ? p2 : p1;
+            const bool nearV = firstIsC1 ? v1 : v2, farV = firstIsC1 ? v2 : v1;
+            uint32_t next;
+            if (nearV) {
+                if (farV) {
+                    if (sp < STACK) stk[sp * stride] = farP;
+                    sp++;
+                }
+                next = nearP;
+            } else if (farV) {
+                next = farP;
+            } else if (sp > 0) {
+                sp--;
+                next = stk[sp * stride];
+            } else {
+                alive = false;
+                next = 1u << 28;  // leave the inner loop
+            }
+            index = next & 0x0FFFFFFFu;
+            count = next >> 28;
+        }
+        if (alive) {  // leaf; the next record is fetched while the current one is tested
+            TriRec cur = load_tri(tris, index);
+            for (uint32_t i = 0; i < count; i++) {
+                TriRec nxt = cur;
+                if (i + 1 < count) nxt = load_tri(tris, index + i + 1);
+                const int code = tri_hit<false, true>(cur, index + i, ray, h, win, cnt);
+                if (code == 2 && hitResult && !shadow) tie = true;  // equal t with the current best of THIS mesh
+                hitResult |= code == 1;
+                cur = nxt;
+            }
+            if (tie) alive = false;
+            if (shadow && hitResult) {
+                alive = false;
+            } else if (sp > 0) {
+                sp--;
+                const uint32_t next = stk[sp * stride];
+                index = next & 0x0FFFFFFFu;
+                count = next >> 28;
+            } else {
+                alive = false;
+            }
+        }
+    }
+    if (hitResult && !shadow && !tie) {
+        const uint32_t face = mesh.fast.elements[win.slot];
+        h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
+        h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
+    }
+    return hitResult;
+}
+
 // The counting variant walks the reference's tree; the fast variant walks the SAH tree and
 // falls back to the reference's on an exact tie (see DevMesh).
 template <int STACK, bool STATS, bool CULL>
@@ -443,7 +565,7 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
     bool tie = false;
     if (!CULL) return mesh_walk<STACK, STATS, false, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, tie);
     const Hit h0 = h;
-    bool r = mesh_walk<STACK, STATS, CULL, true>(mesh, mesh.fast.bvh, mesh.fast.tri, mesh.fast.elements, ray, shadow, h, stk, cnt, stride, tie);
+    bool r = mesh_walk_fast<STACK>(mesh, ray, shadow, h, stk, cnt, stride, tie);
     if (tie) {  // rare: two accepted triangles with bitwise-equal t — the reference's test order decides
         h = h0;
         bool t2 = false;
@@ -488,9 +610,6 @@ template <int STACK, bool CULL>
 __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                               const uint32_t stride, const float4* lds_nodes) {
     if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
-    const bool zeroDir = ray.dir.x == 0 || ray.dir.y == 0 || ray.dir.z == 0;
-    if (__any(zeroDir) || mesh.any_empty_box)  // literal special-case form: every lane of the group walks alone
-        return mesh_hit<STACK, false, CULL>(mesh, ray, shadow, h, stk, cnt, stride);
     const Hit h0 = h;
     bool tie = false;
     const float4* bvh = mesh.fast.bvh;
@@ -502,15 +621,12 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
     const uint32_t axis = sub < 6u ? sub - 3u * child : 0u;
     const uint32_t o0 = sub < 6u ? child * 8u + axis : (sub == 6u ? 3u : 11u);       // bmin[axis] | child.index
     const uint32_t o1 = sub < 6u ? child * 8u + 4u + axis : (sub == 6u ? 7u : 15u);  // bmax[axis] | child.count
-    const float p_a = axis == 0 ? ray.p.x : axis == 1 ? ray.p.y : ray.p.z;
-    const float d_a = axis == 0 ? ray.dir.x : axis == 1 ? ray.dir.y : ray.dir.z;
-    const double rcp_a = 1.0 / (double)d_a;
-    // this lane's share of the cull test (see cull_limits): its own axis
-    float lim_a = 0.0f;
-    if (CULL) {
-        const float pm = fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z)));
-        lim_a = 1e-4f * (mesh.scale > pm ? mesh.scale : pm) / fabsf(d_a);
-    }
+    // this lane's slab of the conservative box test (see fast_ray / fast_box)
+    const FastRay fr = fast_ray(ray, mesh.scale);
+    const float r_a = axis == 0 ? fr.r.x : axis == 1 ? fr.r.y : fr.r.z;
+    const float cn_a = axis == 0 ? fr.cn.x : axis == 1 ? fr.cn.y : fr.cn.z;
+    const float cf_a = axis == 0 ? fr.cf.x : axis == 1 ? fr.cf.y : fr.cf.z;
+    const bool pos_a = r_a >= 0;
     bool hitResult = false;
     TriWin win;
     win.slot = 0;
@@ -529,28 +645,19 @@ __device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, con
                 const float* pair = reinterpret_cast<const float*>(bvh + 2 * index);
                 w0 = pair[o0]; w1 = pair[o1];
             }
-            // lanes 0..5: one slab (objFunctions.cpp:223-240)
-            float t0 = fdiv(w0 - p_a, rcp_a), t1 = fdiv(w1 - p_a, rcp_a);
-            const bool sw = t0 > t1;
-            const float a0 = sw ? t1 : t0, a1 = sw ? t0 : t1;
-            // lanes 0 and 3 gather y,z of their child: tEntry = max(max(x,y),z), tExit = min(min(x,y),z)
+            // lanes 0..5: one slab of one child (fast_box)
+            const float a0 = fmaf(pos_a ? w0 : w1, r_a, cn_a), a1 = fmaf(pos_a ? w1 : w0, r_a, cf_a);
+            // lanes 0 and 3 gather y,z of their child
             const float y0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x101, 0xF, 0xF, true));  // row_shl:1
             const float z0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x102, 0xF, 0xF, true));  // row_shl:2
             const float y1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x101, 0xF, 0xF, true));
             const float z1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x102, 0xF, 0xF, true));
-            const float e = smax(smax(a0, y0), z0), x = smin(smin(a1, y1), z1);
-            float t = (e <= x && e < RTU_BIGFLOAT) ? (float)((double)e + 0.01) : RTU_BIGFLOAT;  // :516-521
-            bool v = t != RTU_BIGFLOAT;
-            if (CULL) {  // lanes 0..5 test their own axis; lanes 0 and 3 gather the verdicts of their child
-                const float mySkip = ((a0 - lim_a > h.z) || (a1 < -lim_a)) ? 1.0f : 0.0f;
-                const float s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mySkip), 0x101, 0xF, 0xF, true));
-                const float s2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mySkip), 0x102, 0xF, 0xF, true));
-                v = v && mySkip == 0.0f && s1 == 0.0f && s2 == 0.0f;
-            }
+            const float t = fmaxf(fmaxf(a0, y0), z0), x = fminf(fminf(a1, y1), z1);
+            const float tv = (t <= x && t <= h.z && x >= 0.0f) ? t : __builtin_inff();  // +inf: do not visit
             const float pk = __uint_as_float(__float_as_uint(w0) | (__float_as_uint(w1) << 28));  // lanes 6,7
             // every lane fetches both children's verdicts and decides identically
-            const float tA = grp_bcast(t, 0), tB = grp_bcast(t, 3);
-            const bool vA = grp_bcast(v ? 1.0f : 0.0f, 0) != 0.0f, vB = grp_bcast(v ? 1.0f : 0.0f, 3) != 0.0f;
+            const float tA = grp_bcast(tv, 0), tB = grp_bcast(tv, 3);
+            const bool vA = tA < __builtin_inff(), vB = tB < __builtin_inff();
             const uint32_t pA = __float_as_uint(grp_bcast(pk, 6)), pB = __float_as_uint(grp_bcast(pk, 7));
             const bool firstIsC1 = tA <= tB;  // :361-389
             const uint32_t nearP = firstIsC1 ? pA : pB, farP = firstIsC1 ? pB : pA;

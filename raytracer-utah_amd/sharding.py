@@ -12,6 +12,41 @@ def gather_framebuffer(shard, gathered, dist):
     return gathered
 
 
+class FramePipeline:
+    """Double-buffered frame loop of one rank: frame i is rendered into shard buffer i % 2 and its
+    all_gather is issued asynchronously, so the collective (RCCL's own stream) overlaps the kernels
+    of frame i+1, which write the other buffer. begin(i) makes the current stream wait for the
+    gather that last read buffer i % 2 (frame i-2); drain() waits for everything in flight.
+    staged=True (rehearsal on gloo): the collective runs on host copies of the buffers."""
+
+    def __init__(self, shards, gathers, dist, staged=False):
+        self.shards, self.gathers, self.dist, self.staged = shards, gathers, dist, staged
+        self.work = [None, None]
+        self.last = None
+
+    def begin(self, i):
+        b = i & 1
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        return self.shards[b]
+
+    def gather(self, i):
+        b = i & 1
+        src = self.shards[b].cpu() if self.staged else self.shards[b]
+        self.work[b] = self.dist.all_gather_into_tensor(self.gathers[b], src, async_op=True)
+        self.last = b
+
+    def drain(self):
+        for b in (0, 1):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+
+    def last_gathered(self):
+        return self.gathers[self.last]
+
+
 def assemble_gathered(pkg, gathered_np, camera, width, height, world):
     """De-interleave a gathered [world, max_rows, W, 4] array into the [H, W, 4] frame."""
     frames = [pkg.frame_setup(camera, width, height, shard_rank=r, shard_count=world) for r in range(world)]

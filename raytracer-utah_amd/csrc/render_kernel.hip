@@ -256,13 +256,12 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     flush_counters<STATS>(a, cnt);
 }
 
-// Stage the top of every mesh's BVH (BFS order) into the workgroup's LDS node area.
-template <int STACK>
+// Stage the top of every mesh's 8-wide tree (BFS order) into the workgroup's LDS node area.
 __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nodes) {
     const RTU_CONST DevMesh* meshes = as_const(a.scene.meshes);
     for (uint32_t m = 0; m < a.n_meshes; m++) {
-        const float4* src = meshes[m].fast.bvh;
-        const uint32_t n = meshes[m].lds_nodes * 2u, off = meshes[m].lds_off;
+        const float4* src = meshes[m].bvh8;
+        const uint32_t n = meshes[m].lds_nodes * 16u, off = meshes[m].lds_off;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_nodes[off + i] = src[i];
     }
     __syncthreads();
@@ -300,8 +299,8 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
 template <int STACK>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2C);
-    __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
-    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
+    __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
+    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
     const NarrowGeom g = narrow_geom(a, 0);
     if (g.R != 8u) return;
     const uint32_t grp = threadIdx.x >> 3;
@@ -312,7 +311,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
     if (blockIdx.x >= chunks) return;  // nothing for this workgroup: do not stage the tree
-    stage_nodes<STACK>(a, s_nodes);
+    stage_nodes(a, s_nodes);
     if (grp >= groups) return;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
@@ -327,7 +326,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
         const int x = (int)(pix - ly * (uint32_t)a.frame.width);
         const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
         bool deferred;
-        primary_pixel<STACK, false, false, true>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
+        primary_pixel<RTU_STACK8, false, false, true>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
@@ -446,8 +445,8 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
 template <int STACK>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
-    __shared__ float4 s_nodes[RTU_LDS_NODE_F4(STACK)];
-    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * STACK];
+    __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
+    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
     const NarrowGeom g = narrow_geom(a, ph);
     if (g.R != 8u) return;
     const uint32_t grp = threadIdx.x >> 3;
@@ -456,7 +455,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
     const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
     if (blockIdx.x >= chunks) return;
-    stage_nodes<STACK>(a, s_nodes);
+    stage_nodes(a, s_nodes);
     if (grp >= groups) return;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
@@ -466,7 +465,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
         const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<STACK, false, false, true>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
+        frame_ray<RTU_STACK8, false, false, true>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 

@@ -213,6 +213,61 @@ void build_sah(const RtuMesh& m, SahTree& out) {
     }
 }
 
+// The binary SAH tree collapsed to eight children per node (for the cooperative walk, one child
+// per lane): starting from a node's two children, the inner child with the largest surface area
+// is replaced by ITS two children until eight are reached or only leaves remain. Breadth-first,
+// so that the top of the tree is the prefix staged into LDS. Same leaves, same boxes.
+void build_wide8(const SahTree& t, std::vector<float4>& out) {
+    struct Job { uint32_t bin, id; };
+    out.assign(16, make_float4(0, 0, 0, 0));
+    std::vector<Job> queue;
+    queue.push_back({1u, 0u});
+    auto area = [&](uint32_t b) {
+        const RtuBvhNode& n = t.nodes[b];
+        float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const Job j = queue[qi];
+        std::vector<uint32_t> set;
+        if (t.nodes[j.bin].count != 0) {
+            set.push_back(j.bin);  // a mesh of <= 8 triangles: the root is a leaf
+        } else {
+            set.push_back(t.nodes[j.bin].index);
+            set.push_back(t.nodes[j.bin].index + 1);
+            while (set.size() < 8) {
+                int best = -1;
+                float bestA = -1.0f;
+                for (size_t i = 0; i < set.size(); i++)
+                    if (t.nodes[set[i]].count == 0 && area(set[i]) > bestA) { bestA = area(set[i]); best = (int)i; }
+                if (best < 0) break;
+                const uint32_t b = set[(size_t)best];
+                set[(size_t)best] = t.nodes[b].index;
+                set.push_back(t.nodes[b].index + 1);
+            }
+        }
+        for (uint32_t c = 0; c < 8; c++) {
+            float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0);
+            uint32_t ref = RTU_REF8_EMPTY;
+            if (c < set.size()) {
+                const RtuBvhNode& n = t.nodes[set[c]];
+                lo = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], 0);
+                hi = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0);
+                if (n.count != 0) {
+                    ref = n.index | (n.count << 28);
+                } else {
+                    ref = (uint32_t)(out.size() / 16);
+                    out.resize(out.size() + 16, make_float4(0, 0, 0, 0));
+                    queue.push_back({set[c], ref});
+                }
+            }
+            memcpy(&lo.w, &ref, 4);
+            out[(size_t)j.id * 16 + 2 * c] = lo;
+            out[(size_t)j.id * 16 + 2 * c + 1] = hi;
+        }
+    }
+}
+
 // 64-byte triangle records (TriRec, rtu_intersect.h) in the order of `elements`: the
 // ray-independent part of TriObj::IntersectTriangle (objFunctions.cpp:259-300) evaluated with
 // the same float ops.
@@ -562,7 +617,10 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if ((rc = upload(ctx, reinterpret_cast<const float4*>(sah.nodes.data()), sah.nodes.size() * 2, &d.fast.bvh)) != RTU_OK) return rc;
         if ((rc = upload(ctx, tri.data(), tri.size(), &d.fast.tri)) != RTU_OK) return rc;
         if ((rc = upload(ctx, sah.elements.data(), sah.elements.size(), &d.fast.elements)) != RTU_OK) return rc;
-        fast_nodes[mi] = (uint32_t)sah.nodes.size();
+        std::vector<float4> wide8;
+        build_wide8(sah, wide8);
+        if ((rc = upload(ctx, wide8.data(), wide8.size(), &d.bvh8)) != RTU_OK) return rc;
+        fast_nodes[mi] = (uint32_t)(wide8.size() / 16);
         if (sah.depth > stack_needed) stack_needed = sah.depth;
         if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;
@@ -577,18 +635,15 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if (m.bvh_depth > stack_needed) stack_needed = m.bvh_depth;
     }
 
-    // LDS node areas of the cooperative kernels (RTU_LDS_NODE_F4 of the STACK variant that
-    // rtu_launch_frame will pick), handed out in mesh order
+    // LDS node area of the cooperative kernels, handed out in mesh order
     {
-        uint32_t stack_sel = stack_needed <= 16 ? 16 : stack_needed <= 24 ? 24 : stack_needed <= 32 ? 32 : RTU_MAX_BVH_STACK;
-        uint32_t budget = (uint32_t)RTU_LDS_NODE_F4(stack_sel) / 2;  // nodes
+        uint32_t budget = (uint32_t)RTU_LDS_NODE_F4 / 16;  // node8
         uint32_t used = 0;
         for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
             uint32_t take = fast_nodes[mi];
             if (take > budget - used) take = budget - used;
-            take &= ~1u;  // whole sibling pairs
             meshes[mi].lds_nodes = take;
-            meshes[mi].lds_off = used * 2;
+            meshes[mi].lds_off = used * 16;
             used += take;
         }
     }

@@ -52,7 +52,10 @@ struct DevMesh {
     float    bmin[3], bmax[3];
     uint32_t n_bvh_nodes, n_elements;
     uint32_t any_empty_box;     // some BVH box has min > max (cannot come from triangles)
-    uint32_t lds_nodes;         // nodes [0, lds_nodes) are staged in LDS by the cooperative kernels (BFS order: the top of the tree)
+    const float4* bvh8;         // the fast tree collapsed to 8 children per node for the cooperative walk: node i =
+                                // float4[16 i ..]: child c = {bmin.xyz, ref} {bmax.xyz, -}; ref = index | count << 28 like the
+                                // binary nodes (count == 0: node8 index), RTU_REF8_EMPTY for an unused slot; breadth-first
+    uint32_t lds_nodes;         // node8 [0, lds_nodes) are staged in LDS by the cooperative kernels (the top of the tree)
     uint32_t lds_off;           // their offset in the block's LDS node area, in float4
     float    scale;             // largest |coordinate| of the mesh's bounding box (cull margin, rtu_intersect.h)
 };
@@ -119,7 +122,10 @@ struct LevelBuffers {
 #define RTU_COOP_THREADS 1024
 #define RTU_COOP_GROUPS  (RTU_COOP_THREADS / 8)
 #define RTU_LDS_BYTES    163840
-#define RTU_LDS_NODE_F4(STACK) ((RTU_LDS_BYTES - RTU_COOP_GROUPS * (STACK) * 4) / 16)
+#define RTU_STACK8       64   // stack entries per ray of the cooperative walk (8-wide tree: up to 7 pushes per step;
+                              // a ray that would need more is finished on the reference's tree, like an exact tie)
+#define RTU_REF8_EMPTY   0x0FFFFFFFu
+#define RTU_LDS_NODE_F4  ((RTU_LDS_BYTES - RTU_COOP_GROUPS * RTU_STACK8 * 4) / 16)
 
 #define RTU_SHARDS 64
 #define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_kernel.hip)

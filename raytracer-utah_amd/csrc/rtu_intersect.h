@@ -575,108 +575,83 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
 }
 
 // ---------------------------------------------------------------------------
-// COOPERATIVE BVH WALK: eight lanes per ray.
+// COOPERATIVE BVH WALK: eight lanes per ray, on the fast tree collapsed to EIGHT children per
+// node (DevMesh::bvh8).
 //
-// Measured (profiles/r01_*): a lone wavefront issues one VALU instruction per ~4.5
-// cycles, an inner BVH step is ~130 instructions and a leaf round up to 4 x ~110, so a
-// ray that needs 100+ steps holds its wavefront — and, being the slowest, the whole
-// phase — for hundreds of microseconds while the chip idles. The steps of ONE ray are
-// inherently sequential (near-first order), but the work INSIDE a step is not:
-//   inner step: 2 children x 3 axes x 2 planes = 12 exact quotients -> lanes 0..5 of the
-//               group do one (child, axis) slab each, lanes 6,7 fetch the child words;
+// Measured (profiles/r01_*): the steps of one ray are sequential and each costs a dependent
+// fetch plus ~50-100 instructions at one instruction per ~4.5 cycles; a ray with 100+ steps
+// holds its wavefront — and, being the slowest, the whole phase — while the chip idles. The
+// steps of ONE ray cannot overlap, but eight lanes can do more per step:
+//   inner step: lane c tests child c of the node (fast_box: six fma), the hit children are
+//               ranked by entry distance across the group (seven ds_swizzle exchanges) and pushed
+//               on the ray's LDS stack in one go, nearest on top — a third of the depth of the
+//               binary tree, the same instruction count per step;
 //   leaf round: up to 8 triangles -> one triangle per lane, then a min-t reduction with
 //               the lower element index winning a tie (= the reference's strict `t < z`
 //               applied in element order, objFunctions.cpp:270,394-396).
 // All eight lanes hold the same ray and keep identical copies of the walk state (h.z,
 // winner, stack pointer), so every lane takes the same branches; values move between lanes
-// with ds_swizzle / ds_bpermute (no LDS memory). Same visiting order, same float
-// operations, same results as mesh_hit — only the latency per step drops ~3x.
-__device__ __forceinline__ float grp_bcast(float v, int srcSub) {  // value of sub-lane srcSub of my 8-lane group
-    int r;
-    switch (srcSub) {  // ds_swizzle bitmask mode: lane' = (lane & 0x18) | srcSub
-        case 0: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (0 << 5)); break;
-        case 3: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (3 << 5)); break;
-        case 6: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (6 << 5)); break;
-        default: r = __builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (7 << 5)); break;
-    }
-    return __int_as_float(r);
-}
+// with ds_swizzle / ds_bpermute. The visiting order only affects speed (see mesh_walk_fast);
+// the triangle arithmetic is the reference's.
 template <int M>
 __device__ __forceinline__ int grp_xor(int v) {  // value of lane ^ M
     return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));
 }
 
-template <int STACK, bool CULL>
-__device__ __forceinline__ bool mesh_hit_coop(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+// The caller has established that the ray passes the mesh's bounding box.
+template <int STACK, bool CULL, class MeshT>
+__device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                               const uint32_t stride, const float4* lds_nodes) {
-    if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
     const Hit h0 = h;
     bool tie = false;
-    const float4* bvh = mesh.fast.bvh;
+    const float4* bvh8 = mesh.bvh8;
     const float4* tris = mesh.fast.tri;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & 7u;
-    // role of this lane in an inner step
-    const uint32_t child = sub >= 3u ? 1u : 0u;
-    const uint32_t axis = sub < 6u ? sub - 3u * child : 0u;
-    const uint32_t o0 = sub < 6u ? child * 8u + axis : (sub == 6u ? 3u : 11u);       // bmin[axis] | child.index
-    const uint32_t o1 = sub < 6u ? child * 8u + 4u + axis : (sub == 6u ? 7u : 15u);  // bmax[axis] | child.count
-    // this lane's slab of the conservative box test (see fast_ray / fast_box)
+    const uint32_t ldsN = mesh.lds_nodes, ldsOff = mesh.lds_off;
     const FastRay fr = fast_ray(ray, mesh.scale);
-    const float r_a = axis == 0 ? fr.r.x : axis == 1 ? fr.r.y : fr.r.z;
-    const float cn_a = axis == 0 ? fr.cn.x : axis == 1 ? fr.cn.y : fr.cn.z;
-    const float cf_a = axis == 0 ? fr.cf.x : axis == 1 ? fr.cf.y : fr.cf.z;
-    const bool pos_a = r_a >= 0;
     bool hitResult = false;
     TriWin win;
     win.slot = 0;
     win.bc = mk3(0, 0, 0);
-    int sp = 0;
-    float4 r0 = bvh[2], r1 = bvh[3];  // root = node 1
-    uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
+    uint32_t sp = 0;
+    uint32_t index = 0, count = 0;  // root = node8 0
     bool alive = true;
     while (alive) {
-        while (alive && count == 0) {  // inner node: all eight lanes cooperate
-            float w0, w1;
-            if (index < mesh.lds_nodes) {  // the top of the tree lives in LDS (staged once per workgroup)
-                const float* pair = reinterpret_cast<const float*>(lds_nodes + mesh.lds_off + 2 * index);
-                w0 = pair[o0]; w1 = pair[o1];
-            } else {
-                const float* pair = reinterpret_cast<const float*>(bvh + 2 * index);
-                w0 = pair[o0]; w1 = pair[o1];
-            }
-            // lanes 0..5: one slab of one child (fast_box)
-            const float a0 = fmaf(pos_a ? w0 : w1, r_a, cn_a), a1 = fmaf(pos_a ? w1 : w0, r_a, cf_a);
-            // lanes 0 and 3 gather y,z of their child
-            const float y0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x101, 0xF, 0xF, true));  // row_shl:1
-            const float z0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x102, 0xF, 0xF, true));  // row_shl:2
-            const float y1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x101, 0xF, 0xF, true));
-            const float z1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a1), 0x102, 0xF, 0xF, true));
-            const float t = fmaxf(fmaxf(a0, y0), z0), x = fminf(fminf(a1, y1), z1);
-            const float tv = (t <= x && t <= h.z && x >= 0.0f) ? t : __builtin_inff();  // +inf: do not visit
-            const float pk = __uint_as_float(__float_as_uint(w0) | (__float_as_uint(w1) << 28));  // lanes 6,7
-            // every lane fetches both children's verdicts and decides identically
-            const float tA = grp_bcast(tv, 0), tB = grp_bcast(tv, 3);
-            const bool vA = tA < __builtin_inff(), vB = tB < __builtin_inff();
-            const uint32_t pA = __float_as_uint(grp_bcast(pk, 6)), pB = __float_as_uint(grp_bcast(pk, 7));
-            const bool firstIsC1 = tA <= tB;  // :361-389
-            const uint32_t nearP = firstIsC1 ? pA : pB, farP = firstIsC1 ? pB : pA;
-            const bool nearV = firstIsC1 ? vA : vB, farV = firstIsC1 ? vB : vA;
+        while (alive && count == 0) {  // inner node: lane `sub` tests child `sub`
+            const float4* nd = (index < ldsN ? lds_nodes + ldsOff : bvh8) + ((size_t)index * 8u + sub) * 2u;
+            const float4 c0 = nd[0], c1 = nd[1];
+            float tn;
+            const uint32_t ref = __float_as_uint(c0.w);
+            const bool valid = fast_box(fr, c0, c1, h.z, tn) && ref != RTU_REF8_EMPTY;
+            const uint32_t m8 = (uint32_t)(__ballot(valid) >> (lane & 56u)) & 0xFFu;
             uint32_t next;
-            if (nearV) {
-                if (farV) {
-                    if (sp < STACK) stk[sp * stride] = farP;  // eight identical stores to the group's column
-                    sp++;
+            if (m8 == 0) {
+                if (sp > 0) {
+                    sp--;
+                    next = stk[sp * stride];
+                } else {
+                    alive = false;
+                    next = 1u << 28;
                 }
-                next = nearP;
-            } else if (farV) {
-                next = farP;
-            } else if (sp > 0) {
-                sp--;
-                next = stk[sp * stride];
             } else {
-                alive = false;
-                next = 1u << 28;
+                const uint32_t n = (uint32_t)__popc(m8);
+                if (sp + n > (uint32_t)RTU_STACK8) {  // would not fit (group-uniform): finish on the reference's tree
+                    tie = true;
+                    alive = false;
+                    next = 1u << 28;
+                } else {
+                    // sortable key: entry distance, the child index in the low bits makes it unique
+                    const uint32_t tb = __float_as_uint(tn);
+                    const int key = valid ? (int)(((tb ^ ((tb >> 31) ? 0xFFFFFFFFu : 0x80000000u)) & ~7u) | sub) ^ (int)0x80000000 : 0x7FFFFFFF;
+                    uint32_t rank = 0;
+                    rank += grp_xor<1>(key) < key; rank += grp_xor<2>(key) < key; rank += grp_xor<3>(key) < key;
+                    rank += grp_xor<4>(key) < key; rank += grp_xor<5>(key) < key; rank += grp_xor<6>(key) < key;
+                    rank += grp_xor<7>(key) < key;
+                    if (valid) stk[(sp + n - 1u - rank) * stride] = ref;  // nearest on top
+                    sp += n - 1u;
+                    next = stk[sp * stride];
+                }
             }
             index = next & 0x0FFFFFFFu;
             count = next >> 28;

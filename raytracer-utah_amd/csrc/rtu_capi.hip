@@ -268,6 +268,64 @@ void build_wide8(const SahTree& t, std::vector<float4>& out) {
     }
 }
 
+// ... and to FOUR children per node for the one-lane-per-ray walk (half the dependent fetches of the
+// binary tree at the same instruction count). A node is 8 float4, structure of arrays so that a lane
+// picks the near / far plane arrays by the sign of its ray: {min.x[4]} {min.y[4]} {min.z[4]}
+// {max.x[4]} {max.y[4]} {max.z[4]} {ref[4]} {-}. stack_need: the deepest stack a walk can build
+// (a step pushes all hit children but the nearest).
+void build_wide4(const SahTree& t, std::vector<float4>& out, uint32_t& stack_need) {
+    struct Job { uint32_t bin, id, pushed; };
+    out.assign(8, make_float4(0, 0, 0, 0));
+    std::vector<Job> queue;
+    queue.push_back({1u, 0u, 0u});
+    stack_need = 1;
+    auto area = [&](uint32_t b) {
+        const RtuBvhNode& n = t.nodes[b];
+        float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        const Job j = queue[qi];
+        std::vector<uint32_t> set;
+        if (t.nodes[j.bin].count != 0) {
+            set.push_back(j.bin);
+        } else {
+            set.push_back(t.nodes[j.bin].index);
+            set.push_back(t.nodes[j.bin].index + 1);
+            while (set.size() < 4) {
+                int best = -1;
+                float bestA = -1.0f;
+                for (size_t i = 0; i < set.size(); i++)
+                    if (t.nodes[set[i]].count == 0 && area(set[i]) > bestA) { bestA = area(set[i]); best = (int)i; }
+                if (best < 0) break;
+                const uint32_t b = set[(size_t)best];
+                set[(size_t)best] = t.nodes[b].index;
+                set.push_back(t.nodes[b].index + 1);
+            }
+        }
+        const uint32_t pushed = j.pushed + (uint32_t)set.size() - 1u;
+        if (pushed + 1u > stack_need) stack_need = pushed + 1u;
+        float v[7][4];
+        for (uint32_t c = 0; c < 4; c++) {
+            for (int k = 0; k < 3; k++) { v[k][c] = INFINITY; v[3 + k][c] = -INFINITY; }
+            uint32_t ref = RTU_REF8_EMPTY;
+            if (c < set.size()) {
+                const RtuBvhNode& n = t.nodes[set[c]];
+                for (int k = 0; k < 3; k++) { v[k][c] = n.bmin[k]; v[3 + k][c] = n.bmax[k]; }
+                if (n.count != 0) {
+                    ref = n.index | (n.count << 28);
+                } else {
+                    ref = (uint32_t)(out.size() / 8);
+                    out.resize(out.size() + 8, make_float4(0, 0, 0, 0));
+                    queue.push_back({set[c], ref, pushed});
+                }
+            }
+            memcpy(&v[6][c], &ref, 4);
+        }
+        for (int r = 0; r < 7; r++) out[(size_t)j.id * 8 + r] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+    }
+}
+
 // 64-byte triangle records (TriRec, rtu_intersect.h) in the order of `elements`: the
 // ray-independent part of TriObj::IntersectTriangle (objFunctions.cpp:259-300) evaluated with
 // the same float ops.
@@ -621,6 +679,13 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         build_wide8(sah, wide8);
         if ((rc = upload(ctx, wide8.data(), wide8.size(), &d.bvh8)) != RTU_OK) return rc;
         fast_nodes[mi] = (uint32_t)(wide8.size() / 16);
+        std::vector<float4> wide4;
+        uint32_t need4 = 1;
+        build_wide4(sah, wide4, need4);
+        if ((rc = upload(ctx, wide4.data(), wide4.size(), &d.bvh4)) != RTU_OK) return rc;
+        if (need4 > RTU_MAX_BVH_STACK) need4 = RTU_MAX_BVH_STACK;  // a walk that needs more finishes on the reference's tree
+        if (need4 > stack_needed) stack_needed = need4;
+        if (getenv("RTU_VERBOSE")) fprintf(stderr, "mesh %u: %u faces, sah depth %u, node4 %zu (stack %u), node8 %zu\n", mi, m.nf, sah.depth, wide4.size() / 8, need4, wide8.size() / 16);
         if (sah.depth > stack_needed) stack_needed = sah.depth;
         if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;

@@ -55,6 +55,8 @@ struct DevMesh {
     const float4* bvh8;         // the fast tree collapsed to 8 children per node for the cooperative walk: node i =
                                 // float4[16 i ..]: child c = {bmin.xyz, ref} {bmax.xyz, -}; ref = index | count << 28 like the
                                 // binary nodes (count == 0: node8 index), RTU_REF8_EMPTY for an unused slot; breadth-first
+    const float4* bvh4;         // ... and to 4 children per node for the one-lane-per-ray walk: node i = float4[8 i ..]:
+                                // {min.x[4]} {min.y[4]} {min.z[4]} {max.x[4]} {max.y[4]} {max.z[4]} {ref[4]} {-}
     uint32_t lds_nodes;         // node8 [0, lds_nodes) are staged in LDS by the cooperative kernels (the top of the tree)
     uint32_t lds_off;           // their offset in the block's LDS node area, in float4
     float    scale;             // largest |coordinate| of the mesh's bounding box (cull margin, rtu_intersect.h)

@@ -479,41 +479,55 @@ __device__ __forceinline__ bool fast_box(const FastRay& f, float4 lo, float4 hi,
 // The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
 // the order only affects speed: an exact tie between two accepted triangles, the one case where
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
-template <int STACK>
-__device__ __forceinline__ bool mesh_walk_fast(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
+template <int STACK, class MeshT>
+__device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                                const uint32_t stride, bool& tie) {
-    const float4* bvh = mesh.fast.bvh;
+    // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches.
+    const float4* bvh4 = mesh.bvh4;
     const float4* tris = mesh.fast.tri;
     const FastRay fr = fast_ray(ray, mesh.scale);
+    // near / far plane arrays of a node, by the sign of the ray (see build_wide4)
+    const uint32_t onx = fr.px ? 0u : 3u, ofx = 3u - onx, ony = fr.py ? 1u : 4u, ofy = 5u - ony, onz = fr.pz ? 2u : 5u, ofz = 7u - onz;
     bool hitResult = false;
     TriWin win;
     win.slot = 0;
     win.bc = mk3(0, 0, 0);
     int sp = 0;
-    float4 r0 = bvh[2], r1 = bvh[3];  // root = node 1 (cyBVH.h:76)
-    uint32_t index = __float_as_uint(r0.w), count = __float_as_uint(r1.w);
+    uint32_t index = 0, count = 0;  // root = node4 0
     bool alive = true;
     while (alive) {
         while (alive && count == 0) {  // inner nodes
-            const float4* pair = bvh + 2 * index;  // children index, index+1: one 64-byte line
-            const float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
-            float t1, t2;
-            const bool v1 = fast_box(fr, a0, a1, h.z, t1);
-            const bool v2 = fast_box(fr, b0, b1, h.z, t2);
-            const bool firstIsC1 = t1 <= t2;
-            const uint32_t p1 = __float_as_uint(a0.w) | (__float_as_uint(a1.w) << 28);
-            const uint32_t p2 = __float_as_uint(b0.w) | (__float_as_uint(b1.w) << 28);
-            const uint32_t nearP = firstIsC1 ? p1 : p2, farP = firstIsC1 ? p2 : p1;
-            const bool nearV = firstIsC1 ? v1 : v2, farV = firstIsC1 ? v2 : v1;
+            const float4* nd = bvh4 + (size_t)index * 8u;
+            const float4 nx = nd[onx], ny = nd[ony], nz = nd[onz], fx = nd[ofx], fy = nd[ofy], fz = nd[ofz], rf = nd[6];
+            const float inf = __builtin_inff();
+#define RTU_CHILD(c)                                                                                                       \
+            const float tn##c = fmaxf(fmaxf(fmaf(nx.c, fr.r.x, fr.cn.x), fmaf(ny.c, fr.r.y, fr.cn.y)), fmaf(nz.c, fr.r.z, fr.cn.z)); \
+            const float tf##c = fminf(fminf(fmaf(fx.c, fr.r.x, fr.cf.x), fmaf(fy.c, fr.r.y, fr.cf.y)), fmaf(fz.c, fr.r.z, fr.cf.z)); \
+            const float k##c = (tn##c <= tf##c && tn##c <= h.z && tf##c >= 0.0f) ? tn##c : inf;
+            RTU_CHILD(x) RTU_CHILD(y) RTU_CHILD(z) RTU_CHILD(w)
+#undef RTU_CHILD
+            // the nearest hit child is next; the other hit children go on the stack
+            const uint32_t rx = __float_as_uint(rf.x), ry = __float_as_uint(rf.y), rz = __float_as_uint(rf.z), rw = __float_as_uint(rf.w);
+            const bool a01 = kx <= ky, a23 = kz <= kw;
+            const float k01 = a01 ? kx : ky, k23 = a23 ? kz : kw;
+            const uint32_t r01 = a01 ? rx : ry, r23 = a23 ? rz : rw;
+            const bool a = k01 <= k23;
+            const float kbest = a ? k01 : k23;
+            const uint32_t rbest = a ? r01 : r23;
             uint32_t next;
-            if (nearV) {
-                if (farV) {
-                    if (sp < STACK) stk[sp * stride] = farP;
-                    sp++;
+            if (kbest < inf) {
+                const int n = (int)(kx < inf) + (int)(ky < inf) + (int)(kz < inf) + (int)(kw < inf);
+                if (sp + n - 1 > STACK) {  // would not fit: finish on the reference's tree
+                    tie = true;
+                    alive = false;
+                    next = 1u << 28;
+                } else {
+                    if (kx < inf && rx != rbest) { stk[sp * stride] = rx; sp++; }
+                    if (ky < inf && ry != rbest) { stk[sp * stride] = ry; sp++; }
+                    if (kz < inf && rz != rbest) { stk[sp * stride] = rz; sp++; }
+                    if (kw < inf && rw != rbest) { stk[sp * stride] = rw; sp++; }
+                    next = rbest;
                 }
-                next = nearP;
-            } else if (farV) {
-                next = farP;
             } else if (sp > 0) {
                 sp--;
                 next = stk[sp * stride];

@@ -94,7 +94,7 @@ struct SahTree {
 
 void build_sah(const RtuMesh& m, SahTree& out) {
     const uint32_t nf = m.nf;
-    uint32_t max_leaf = 8;  // measured: 6-8 beats 4 by 3-5 % (inner steps cost more than triangle tests)
+    uint32_t max_leaf = 4;  // leaves of the one-lane-per-ray walk; the cooperative walk merges subtrees of <= 8 (build_wide8)
     if (const char* e = getenv("RTU_SAH_LEAF")) max_leaf = (uint32_t)atoi(e);  // experiment knob
     if (max_leaf < 1) max_leaf = 1;
     if (max_leaf > 8) max_leaf = 8;
@@ -213,12 +213,47 @@ void build_sah(const RtuMesh& m, SahTree& out) {
     }
 }
 
+// Leaf-order the elements depth-first, so that every subtree owns a contiguous range of element
+// slots (the 8-wide tree of the cooperative walk turns whole subtrees of <= 8 triangles into
+// leaves). first/total: per binary node, the subtree's slot range.
+void dfs_order(SahTree& t, std::vector<uint32_t>& first, std::vector<uint32_t>& total) {
+    std::vector<uint32_t> elems;
+    elems.reserve(t.elements.size());
+    first.assign(t.nodes.size(), 0);
+    total.assign(t.nodes.size(), 0);
+    std::vector<std::pair<uint32_t, int>> stack;  // (node, state)
+    stack.push_back({1u, 0});
+    while (!stack.empty()) {
+        auto [id, st] = stack.back();
+        RtuBvhNode& n = t.nodes[id];
+        if (n.count != 0) {
+            first[id] = (uint32_t)elems.size();
+            total[id] = n.count;
+            for (uint32_t i = 0; i < n.count; i++) elems.push_back(t.elements[n.index + i]);
+            n.index = first[id];
+            stack.pop_back();
+        } else if (st == 0) {
+            first[id] = (uint32_t)elems.size();
+            stack.back().second = 1;
+            stack.push_back({n.index, 0});
+        } else if (st == 1) {
+            stack.back().second = 2;
+            stack.push_back({n.index + 1, 0});
+        } else {
+            total[id] = total[n.index] + total[n.index + 1];
+            stack.pop_back();
+        }
+    }
+    t.elements.swap(elems);
+}
+
 // The binary SAH tree collapsed to eight children per node (for the cooperative walk, one child
 // per lane): starting from a node's two children, the inner child with the largest surface area
 // is replaced by ITS two children until eight are reached or only leaves remain. Breadth-first,
 // so that the top of the tree is the prefix staged into LDS. Same leaves, same boxes.
-void build_wide8(const SahTree& t, std::vector<float4>& out) {
+void build_wide8(const SahTree& t, const std::vector<uint32_t>& first, const std::vector<uint32_t>& total, std::vector<float4>& out) {
     struct Job { uint32_t bin, id; };
+    auto is_leaf = [&](uint32_t b) { return total[b] <= 8u; };  // a subtree of <= 8 triangles is one leaf round for eight lanes
     out.assign(16, make_float4(0, 0, 0, 0));
     std::vector<Job> queue;
     queue.push_back({1u, 0u});
@@ -230,7 +265,7 @@ void build_wide8(const SahTree& t, std::vector<float4>& out) {
     for (size_t qi = 0; qi < queue.size(); qi++) {
         const Job j = queue[qi];
         std::vector<uint32_t> set;
-        if (t.nodes[j.bin].count != 0) {
+        if (is_leaf(j.bin)) {
             set.push_back(j.bin);  // a mesh of <= 8 triangles: the root is a leaf
         } else {
             set.push_back(t.nodes[j.bin].index);
@@ -239,7 +274,7 @@ void build_wide8(const SahTree& t, std::vector<float4>& out) {
                 int best = -1;
                 float bestA = -1.0f;
                 for (size_t i = 0; i < set.size(); i++)
-                    if (t.nodes[set[i]].count == 0 && area(set[i]) > bestA) { bestA = area(set[i]); best = (int)i; }
+                    if (!is_leaf(set[i]) && area(set[i]) > bestA) { bestA = area(set[i]); best = (int)i; }
                 if (best < 0) break;
                 const uint32_t b = set[(size_t)best];
                 set[(size_t)best] = t.nodes[b].index;
@@ -253,8 +288,8 @@ void build_wide8(const SahTree& t, std::vector<float4>& out) {
                 const RtuBvhNode& n = t.nodes[set[c]];
                 lo = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], 0);
                 hi = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0);
-                if (n.count != 0) {
-                    ref = n.index | (n.count << 28);
+                if (is_leaf(set[c])) {
+                    ref = first[set[c]] | (total[set[c]] << 28);
                 } else {
                     ref = (uint32_t)(out.size() / 16);
                     out.resize(out.size() + 16, make_float4(0, 0, 0, 0));
@@ -671,12 +706,14 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         SahTree sah;
         build_sah(m, sah);
         if (sah.depth > RTU_MAX_BVH_STACK) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: SAH tree depth %u > %d", mi, sah.depth, RTU_MAX_BVH_STACK);
+        std::vector<uint32_t> sub_first, sub_total;
+        dfs_order(sah, sub_first, sub_total);
         build_tri_records(m, sah.elements.data(), (uint32_t)sah.elements.size(), tri);
         if ((rc = upload(ctx, reinterpret_cast<const float4*>(sah.nodes.data()), sah.nodes.size() * 2, &d.fast.bvh)) != RTU_OK) return rc;
         if ((rc = upload(ctx, tri.data(), tri.size(), &d.fast.tri)) != RTU_OK) return rc;
         if ((rc = upload(ctx, sah.elements.data(), sah.elements.size(), &d.fast.elements)) != RTU_OK) return rc;
         std::vector<float4> wide8;
-        build_wide8(sah, wide8);
+        build_wide8(sah, sub_first, sub_total, wide8);
         if ((rc = upload(ctx, wide8.data(), wide8.size(), &d.bvh8)) != RTU_OK) return rc;
         fast_nodes[mi] = (uint32_t)(wide8.size() / 16);
         std::vector<float4> wide4;

@@ -1,3 +1,4 @@
-for thr in 100000 200000 400000 800000 2000000; do for t in teapot2_1080 p11_1080; do
-timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu --tag $t --coop-threshold $thr 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"thr $thr $t\", d[\"ms_per_step\"], d[\"roofline\"][\"kernel_ms\"], d[\"config\"][\"z_bit_exact_vs_reference_golden\"])"
+timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for leaf in 1 2 3 4 6 8; do for t in teapot2_1080 p11_1080; do
+RTU_SAH_LEAF=$leaf timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu --tag $t 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"leaf $leaf $t\", d[\"ms_per_step\"], d[\"roofline\"][\"kernel_ms\"], d[\"config\"][\"z_bit_exact_vs_reference_golden\"])"
 done; done

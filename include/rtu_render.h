@@ -122,6 +122,10 @@ int  rtu_frame_status(RtuContext* ctx);
 int  rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, int max_entries, int* slot_out,
                          double* start_us_out, double* end_us_out);
 
+/* Diagnostic: Shade() frames per recursion level (6 values) and rays deferred to stage 2 per phase
+ * (7 values: primary, then levels 0..5) of the most recent frame (fast variant). Synchronises. */
+int  rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out);
+
 /* Counters of the last frame rendered with collect_stats=1 (synchronises). */
 int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
 

@@ -954,6 +954,23 @@ int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz
     return cnt;
 }
 
+int rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out) {
+    if (!ctx || !frames_out || !deferred_out) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    FrameCounters h;
+    RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        frames_out[L] = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) frames_out[L] += h.n_frames[L][s];
+    }
+    for (int p = 0; p <= RTU_MAX_LEVELS; p++) {
+        deferred_out[p] = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) deferred_out[p] += h.n_defer[p][s];
+    }
+    return RTU_OK;
+}
+
 int rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches_out) {
     if (!ctx || !mismatches_out) return RTU_ERR_ARG;
     RTU_HIP(ctx, hipSetDevice(ctx->device));

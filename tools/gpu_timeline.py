@@ -18,6 +18,8 @@ for tag in sys.argv[1:] or ["teapot2_1080"]:
     d = pkg.hip.rtu_device_alloc(ctx._h, W * H * 16)
     for _ in range(3):
         rows = ctx.render_timeline(fr, d)
+    frames, deferred = ctx.frame_counts()
+    print("%s  frames per level %s  deferred rays per phase (primary, L0..L5) %s" % (tag, frames, deferred))
     ms = ctx.time_render(fr, d, None, 20)
     print("%s  %dx%d  (unstamped: %.1f us/frame)" % (tag, W, H, ms * 1e3))
     prev_end = 0.0

@@ -142,6 +142,14 @@ int  rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, v
 int  rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned long long seed,
                            unsigned long long* mismatches_out);
 
+/* Self-test of the sphere / plane intersection routines: the device path evaluates the
+ * reference's expressions in a cheaper order (the bounding-box test last, and only when its
+ * outcome is not already implied); this runs both orders on n_rays random and adversarial rays
+ * (grazing, far away, axis-parallel, origin on the surface) and counts results that differ in
+ * any bit. Expected: 0. */
+int  rtu_selftest_primitives(RtuContext* ctx, unsigned long long n_rays, unsigned long long seed,
+                             unsigned long long* mismatches_out);
+
 /* Device memory helpers so a C/C++ host needs no HIP headers. */
 void* rtu_device_alloc(RtuContext* ctx, size_t bytes);
 void  rtu_device_free(RtuContext* ctx, void* d_ptr);

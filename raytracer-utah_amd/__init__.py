@@ -113,7 +113,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -133,6 +133,7 @@ _sig(hip, "rtu_render_timeline", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _I, c
      ctypes.POINTER(ctypes.c_double))
 _sig(hip, "rtu_get_stats", _I, _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_time_render", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P, _I, ctypes.POINTER(ctypes.c_float))
+_sig(hip, "rtu_selftest_primitives", _I, _P, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong))
 _sig(hip, "rtu_selftest_division", _I, _P, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong))
 _sig(hip, "rtu_device_alloc", _P, _P, ctypes.c_size_t)
 _sig(hip, "rtu_device_free", None, _P, _P)

@@ -689,6 +689,59 @@ __global__ void k_selftest_fdiv(unsigned long long n_pairs, unsigned long long s
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Self-test of the re-ordered sphere / plane tests (rtu_intersect.h): the fast form against the
+// literal reference order, bit for bit (return value, z, front, p, N), on rays built to stress
+// the places where they could differ — grazing the sphere / the square's edge, far away (cancelling
+// discriminant), axis-parallel, starting on the surface, with every incoming h.z regime.
+__global__ void k_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n_rays;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + seed) * 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() {  // uniform in [0,1)
+            x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+            return (float)(x >> 40) * (1.0f / 16777216.0f);
+        };
+        const unsigned mode = (unsigned)(i % 12u);
+        const float scale = mode < 4 ? 3.0f : mode < 6 ? 40.0f : mode < 8 ? 3000.0f : 2.0f;
+        Ray r;
+        r.p = mk3((rnd() * 2 - 1) * scale, (rnd() * 2 - 1) * scale, (rnd() * 2 - 1) * scale);
+        // aim at a point on / near the unit sphere or the unit square, then perturb
+        f3 tgt = mk3(rnd() * 2 - 1, rnd() * 2 - 1, rnd() * 2 - 1);
+        const bool plane = (i & 1u) != 0;
+        if (plane) {
+            tgt.z = 0;
+            if (mode % 3u == 0) tgt.x = (rnd() < 0.5f ? -1.0f : 1.0f) * (1.0f + (rnd() * 2 - 1) * 1e-5f);  // the square's edge
+            if (mode % 3u == 1) tgt.y = (rnd() < 0.5f ? -1.0f : 1.0f) * (1.0f + (rnd() * 2 - 1) * 1e-6f);
+        } else {
+            tgt = norm3(tgt);
+            if (mode % 3u == 0) {  // a ray tangent to the sphere at tgt (+- a hair)
+                f3 tang = norm3(cross3(tgt, mk3(rnd() + 0.1f, rnd() - 0.5f, rnd() - 0.5f)));
+                r.p = tgt * (1.0f + (rnd() * 2 - 1) * 1e-5f) - tang * (rnd() * scale);
+            }
+            if (mode == 9) r.p = tgt;                       // origin on the surface
+            if (mode == 10) r.p = tgt * (rnd() * 0.999f);   // origin inside
+        }
+        r.dir = tgt - r.p;
+        if (mode == 11) { r.dir.x = 0; if (rnd() < 0.5f) r.dir.y = 0; }  // axis-parallel
+        if (rnd() < 0.5f) r.dir = norm3(r.dir);
+        if (rnd() < 0.1f) r.dir = r.dir * (rnd() * 50.0f);
+        const float zsel = rnd();
+        Hit h0;
+        fresh_hit(h0, zsel < 0.4f ? RTU_BIGFLOAT : zsel < 0.7f ? rnd() * 2.0f * scale : rnd() * 0.01f);
+        h0.front = rnd() < 0.5f;
+        Hit a = h0, b = h0;
+        bool ra, rb;
+        if (plane) { ra = plane_hit_t<true>(r, a); rb = plane_hit_t<false>(r, b); }
+        else { ra = sphere_hit_t<true>(r, a); rb = sphere_hit_t<false>(r, b); }
+        auto same = [](float u, float v) { return __float_as_uint(u) == __float_as_uint(v) || (u != u && v != v); };
+        bool ok = ra == rb && same(a.z, b.z) && a.front == b.front;
+        if (ra && rb) ok = ok && same(a.p.x, b.p.x) && same(a.p.y, b.p.y) && same(a.p.z, b.p.z) && same(a.N.x, b.N.x) && same(a.N.y, b.N.y) && same(a.N.z, b.N.z);
+        if (!ok) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 template <int STACK>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
@@ -731,6 +784,11 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
 
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream) {
     hipLaunchKernelGGL(k_selftest_fdiv, dim3(4096), dim3(256), 0, stream, n_pairs, seed, d_mismatches);
+    return (int)hipGetLastError();
+}
+
+int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selftest_prims, dim3(4096), dim3(256), 0, stream, n_rays, seed, d_mismatches);
     return (int)hipGetLastError();
 }
 

@@ -982,6 +982,17 @@ int rtu_selftest_division(RtuContext* ctx, unsigned long long n_pairs, unsigned 
     return RTU_OK;
 }
 
+int rtu_selftest_primitives(RtuContext* ctx, unsigned long long n_rays, unsigned long long seed, unsigned long long* mismatches_out) {
+    if (!ctx || !mismatches_out) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    hipError_t e = (hipError_t)rtu_launch_selftest_prims(n_rays, seed, ctx->counters, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "selftest launch: %s", hipGetErrorString(e));
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RTU_HIP(ctx, hipMemcpy(mismatches_out, ctx->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RTU_OK;
+}
+
 void* rtu_device_alloc(RtuContext* ctx, size_t bytes) {
     if (!ctx || bytes == 0) return nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;

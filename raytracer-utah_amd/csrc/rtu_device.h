@@ -163,6 +163,7 @@ struct KernelArgs {
 // bottom-up) on `stream`. Returns hipError_t as int.
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
 
+int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 
 #endif

@@ -168,19 +168,32 @@ __device__ __forceinline__ bool box_hit(const Ray& r, f3 bmin, f3 bmax, float t_
 // Sphere::IntersectRay (objFunctions.cpp:15-104), including the stale-z
 // fall-through of the n<m branch. uvw is not produced (no
 // textures on this path).
-__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
+//
+// LITERAL = the reference's order: bounding-box test first (:17), then the quadratic.
+// The fast form evaluates the same expressions in a cheaper ORDER (all of them are pure):
+//  * a negative (or NaN) discriminant makes m and n NaN and every branch of :29-:99 false
+//    whatever the box test says -> return before its six divisions;
+//  * the unit sphere lies inside its bounding box, so a ray that really crosses the sphere over a
+//    parameter interval [n, m] crosses every slab over a superset of it, and the float slab
+//    bounds are off by <= 2 ulp each: the box test can fail only if the chord is shorter than
+//    that rounding — or if the float discriminant is itself rounding noise (b*b and 4ac cancel:
+//    absolute error ~4 ulp of b*b). With sqrt(disc) > 4e-3*|b| the discriminant exceeds its own
+//    error 100 times, the true chord exists and is >= 2e-3 of the distance to it, four orders of
+//    magnitude above the slab rounding: the box test is known to pass and is skipped. Otherwise
+//    (grazing, far away, NaN/inf) it is evaluated as in the reference.
+// rtu_selftest_primitives compares both forms bit for bit on random and grazing rays.
+template <bool LITERAL>
+__device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h) {
+    if (LITERAL && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     float a = dot3(ray.dir, ray.dir);
     float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
     float c = dot3(ray.p, ray.p) - 1;
     float sqrtCheck = b * b - 4 * a * c;
-    // The reference tests the unit bounding box first (:17) and then the quadratic. Both are
-    // pure, so the order is free: with a negative (or NaN) discriminant m and n are NaN and
-    // every branch of :29-:99 is false whatever the box test says — skip its six divisions.
-    if (!(sqrtCheck >= 0)) return false;
-    if (!box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
+    if (!LITERAL && !(sqrtCheck >= 0)) return false;
     float sq = sqrtf(sqrtCheck);
     float m = (-b + sq) / (2 * a);
     float n = (-b - sq) / (2 * a);
+    if (!LITERAL && !(sq > 4e-3f * fabsf(b)) && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     bool ret = false;
     if (m == n && m < h.z && (double)m >= 0.001) {
         h.z = m;
@@ -213,17 +226,27 @@ __device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) {
     }
     return ret;
 }
+__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) { return sphere_hit_t<false>(ray, h); }
 
-// Plane::IntersectRay (objFunctions.cpp:107-140)
-__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) {
-    // As in sphere_hit the bounding-box test (:109) is evaluated last: it only matters for a
-    // ray that passes every other condition of :110-:118.
+// Plane::IntersectRay (objFunctions.cpp:107-140). Fast form: the bounding-box test (:109) is
+// evaluated last and only when it can matter. The box is the unit square itself (z from 0 to 0),
+// its z slab is [t, t] with the very t of :111 (0 - p.z == -p.z exactly), so the test asks
+// whether t lies inside the x and y slabs, i.e. whether q = p + dir*t lies inside the square —
+// which :114 has just established in floating point. The two can disagree only within the
+// rounding of q and of the slab bounds, <= 4 ulp * (1 + |p|): the box test is evaluated when q is
+// within 1e-5 * (1 + |p|) of an edge (40x reserve), otherwise it is known to pass.
+template <bool LITERAL>
+__device__ __forceinline__ bool plane_hit_t(const Ray& ray, Hit& h) {
+    if (LITERAL && !box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
     if (ray.dir.z != 0) {
         float t = (-ray.p.z) / (ray.dir.z);
         if ((double)t > 0.001 && t < h.z) {
             f3 q = ray.p + ray.dir * t;
             if (q.x > -1 && q.x < 1 && q.y > -1 && q.y < 1) {
-                if (!box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
+                if (!LITERAL) {
+                    const bool edge = !(fabsf(q.x) < 1.0f - 1e-5f * (1.0f + fabsf(ray.p.x))) || !(fabsf(q.y) < 1.0f - 1e-5f * (1.0f + fabsf(ray.p.y)));
+                    if (edge && !box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
+                }
                 h.front = ray.p.z > 0;
                 h.N = mk3(0, 0, h.front ? 1.0f : -1.0f);
                 h.z = t;
@@ -234,6 +257,7 @@ __device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) {
     }
     return false;
 }
+__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) { return plane_hit_t<false>(ray, h); }
 
 // Point2::Cross (cyPoint.h:247-249)
 __device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return (-ay) * bx + ax * by; }

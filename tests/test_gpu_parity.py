@@ -208,6 +208,14 @@ def test_exact_division(pkg, ctx):
         assert bad.value == 0, "%d quotients differ" % bad.value
 
 
+def test_reordered_primitive_tests_equal_the_literal_order(pkg, ctx):
+    """Sphere / plane: bounding-box test skipped when implied vs the reference's order, 2^28 rays."""
+    for seed in (1, 2026):
+        bad = ctypes.c_ulonglong(123)
+        assert pkg.hip.rtu_selftest_primitives(ctx._h, 1 << 28, seed, ctypes.byref(bad)) == 0
+        assert bad.value == 0
+
+
 def test_errors_are_codes_not_crashes(pkg, ctx, golden):
     g = golden("p1_256")
     scene = g.scene(pkg)

@@ -767,9 +767,8 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 // ---------------------------------------------------------------------------
 // Trace / ShadowTrace (RenderFunctions.cpp:181-240), recursion over the node tree
 // flattened to a pre-order loop. Only h.z (and h.front in the sphere quirk) feeds
-// later intersection tests, so applying FromNodeCoords for the hit node and all of
-// its ancestors immediately is equivalent to the reference applying them as the
-// recursion unwinds.
+// later intersection tests, so FromNodeCoords is applied once, after the loop, to the final
+// hit and its ancestors — equivalent to the reference applying it as the recursion unwinds.
 //
 // ONE instantiation serves both kinds of ray: `shadow` is a per-lane flag, so
 // lanes casting shadow rays and lanes casting reflection / refraction rays walk
@@ -786,6 +785,8 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
     const RTU_CONST DevMesh* meshes = as_const(s.meshes);
     bool any = false;
+    int best = -1;
+    f3 lp = mk3(0, 0, 0), lN = mk3(0, 0, 0);
     deferred = false;
     Ray r0 = to_node(nodes[0], wr);  // ray inside the root node
     Ray rp = r0;                     // ray inside node `rp_node` (cached parent space)
@@ -822,12 +823,19 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
         if (hit) {
             any = true;
-            if (!shadow) {
-                h.node = (int)k;
-                from_node(n, h);
-                for (int j = parent; j >= 0; j = nodes[j].parent) from_node(nodes[j], h);
-            }
+            best = (int)k;  // h.p / h.N are in node k's space
+            lp = h.p;
+            lN = h.N;
         }
+    }
+    // FromNodeCoords for the hit node and its ancestors (scene.h:508-512, applied by the reference as
+    // the recursion unwinds), once, for the final hit: only h.z (and h.front) feed later tests.
+    if (best >= 0 && !shadow) {
+        h.node = best;
+        h.p = lp;
+        h.N = lN;
+        const DevNode* gn = s.nodes;  // per-lane node index: ordinary loads
+        for (int j = best; j >= 0; j = gn[j].parent) from_node(gn[j], h);
     }
     return any;
 }

@@ -182,6 +182,18 @@ __device__ __forceinline__ bool box_hit(const Ray& r, f3 bmin, f3 bmax, float t_
 //    magnitude above the slab rounding: the box test is known to pass and is skipped. Otherwise
 //    (grazing, far away, NaN/inf) it is evaluated as in the reference.
 // rtu_selftest_primitives compares both forms bit for bit on random and grazing rays.
+// The reference compares floats with the double literals 0.001 and 0.00001 (float -> double
+// promotion). Neither is a float, so every float is strictly on one side and the
+// comparison can be done in binary32 against the neighbouring float: with c = 0.001f (the
+// smallest float above 0.001) x >= 0.001 and x > 0.001 both mean x >= c, and x <= 0.001 means
+// x < c; with e = 0.00001f (the largest float below 0.00001) x > 0.00001 means x > e. NaN is false
+// on both sides. A binary64 compare costs a conversion and a quarter-rate instruction.
+// (tests/test_host.py checks the neighbours; rtu_selftest_primitives runs both forms.)
+template <bool LITERAL> __device__ __forceinline__ bool ge_001(float x) { return LITERAL ? (double)x >= 0.001 : x >= 0.001f; }
+template <bool LITERAL> __device__ __forceinline__ bool gt_001(float x) { return LITERAL ? (double)x > 0.001 : x >= 0.001f; }
+template <bool LITERAL> __device__ __forceinline__ bool le_001(float x) { return LITERAL ? (double)x <= 0.001 : x < 0.001f; }
+__device__ __forceinline__ bool gt_00001(float x) { return x > 0.00001f; }
+
 template <bool LITERAL>
 __device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h) {
     if (LITERAL && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
@@ -195,24 +207,24 @@ __device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h) {
     float n = (-b - sq) / (2 * a);
     if (!LITERAL && !(sq > 4e-3f * fabsf(b)) && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     bool ret = false;
-    if (m == n && m < h.z && (double)m >= 0.001) {
+    if (m == n && m < h.z && ge_001<LITERAL>(m)) {
         h.z = m;
         h.front = true;
         ret = true;
-    } else if (m < n && m < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
-        if ((double)m <= 0.001 && (double)n > 0.001 && n < h.z) {
+    } else if (m < n && m < h.z && (ge_001<LITERAL>(m) || ge_001<LITERAL>(n))) {
+        if (le_001<LITERAL>(m) && gt_001<LITERAL>(n) && n < h.z) {
             h.z = n;
             h.front = false;
-        } else if ((double)m > 0.001) {
+        } else if (gt_001<LITERAL>(m)) {
             h.z = m;
             h.front = true;
         }
         ret = true;
-    } else if (n < m && n < h.z && (((double)m >= 0.001) | ((double)n >= 0.001))) {
-        if ((double)n <= 0.001 && (double)m > 0.001 && m < h.z) {
+    } else if (n < m && n < h.z && (ge_001<LITERAL>(m) || ge_001<LITERAL>(n))) {
+        if (le_001<LITERAL>(n) && gt_001<LITERAL>(m) && m < h.z) {
             h.z = m;
             h.front = false;
-        } else if ((double)n > 0.001) {
+        } else if (gt_001<LITERAL>(n)) {
             h.z = n;
             h.front = true;
         }
@@ -240,7 +252,7 @@ __device__ __forceinline__ bool plane_hit_t(const Ray& ray, Hit& h) {
     if (LITERAL && !box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
     if (ray.dir.z != 0) {
         float t = (-ray.p.z) / (ray.dir.z);
-        if ((double)t > 0.001 && t < h.z) {
+        if (gt_001<LITERAL>(t) && t < h.z) {
             f3 q = ray.p + ray.dir * t;
             if (q.x > -1 && q.x < 1 && q.y > -1 && q.y < 1) {
                 if (!LITERAL) {
@@ -303,7 +315,7 @@ __device__ __forceinline__ int tri_hit(const TriRec& T, uint32_t slot, const Ray
     const float dn = dot3(ray.dir, N);
     if (dn != 0) {
         const float t = dot3(A - ray.p, N) / dn;
-        if ((double)t > 0.00001 && (TIE ? t <= h.z : t < h.z)) {  // :270
+        if (gt_00001(t) && (TIE ? t <= h.z : t < h.z)) {  // :270, `t > 0.00001`
             const f3 q = ray.p + ray.dir * t;
             const uint32_t axis = __float_as_uint(T.r3.z);
             const float qx = axis == 0 ? q.y : q.x;

@@ -212,3 +212,28 @@ def test_color24_edge_cases(pkg):
     img.compute_zimage()
     zi = img.zimage()[0]
     assert zi[2] == 0 and zi[7] == 0 and zi[0] == 255  # miss -> 0, farthest -> 0, nearest -> 255
+
+
+def test_float_thresholds_equal_the_double_literals():
+    """The device code compares against 0.001f / 0.00001f in binary32 where the reference promotes
+    to double and compares with 0.001 / 0.00001 (rtu_intersect.h ge_001 ...): equivalent for every
+    float because neither literal is a float. Check the neighbourhood and a random sample."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    c, e = np.float32(0.001), np.float32(0.00001)
+    assert float(c) > 0.001 and float(np.nextafter(c, np.float32(0))) < 0.001
+    assert float(e) < 0.00001 and float(np.nextafter(e, np.float32(1))) > 0.00001
+    xs = [c, e]
+    for base in (c, e):
+        lo = hi = base
+        for _ in range(8):
+            lo, hi = np.nextafter(lo, np.float32(-1)), np.nextafter(hi, np.float32(1))
+            xs += [lo, hi]
+    xs = np.concatenate([np.float32(xs), rng.standard_normal(100000).astype(np.float32) * np.float32(0.002),
+                         np.float32([0, -0.0, np.inf, -np.inf, np.nan, 1e-30, -1e-30])])
+    xd = xs.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(xd >= 0.001, xs >= c)
+        assert np.array_equal(xd > 0.001, xs >= c)
+        assert np.array_equal(xd <= 0.001, xs < c)
+        assert np.array_equal(xd > 0.00001, xs > e)

@@ -94,10 +94,7 @@ struct SahTree {
 
 void build_sah(const RtuMesh& m, SahTree& out) {
     const uint32_t nf = m.nf;
-    uint32_t max_leaf = 4;  // leaves of the one-lane-per-ray walk; the cooperative walk merges subtrees of <= 8 (build_wide8)
-    if (const char* e = getenv("RTU_SAH_LEAF")) max_leaf = (uint32_t)atoi(e);  // experiment knob
-    if (max_leaf < 1) max_leaf = 1;
-    if (max_leaf > 8) max_leaf = 8;
+    const uint32_t max_leaf = 4;  // leaves of the one-lane-per-ray walk; the cooperative walk merges subtrees of <= 8 (build_wide8)
     std::vector<float> bmin(3 * (size_t)nf), bmax(3 * (size_t)nf), cen(3 * (size_t)nf);
     for (uint32_t i = 0; i < nf; i++) {
         const uint32_t* fv = m.f + 3 * i;
@@ -709,7 +706,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         std::vector<uint32_t> sub_first, sub_total;
         dfs_order(sah, sub_first, sub_total);
         build_tri_records(m, sah.elements.data(), (uint32_t)sah.elements.size(), tri);
-        if ((rc = upload(ctx, reinterpret_cast<const float4*>(sah.nodes.data()), sah.nodes.size() * 2, &d.fast.bvh)) != RTU_OK) return rc;
+        d.fast.bvh = nullptr;  // the kernels walk the collapsed forms (bvh4 / bvh8) of this tree
         if ((rc = upload(ctx, tri.data(), tri.size(), &d.fast.tri)) != RTU_OK) return rc;
         if ((rc = upload(ctx, sah.elements.data(), sah.elements.size(), &d.fast.elements)) != RTU_OK) return rc;
         std::vector<float4> wide8;
@@ -722,7 +719,6 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if ((rc = upload(ctx, wide4.data(), wide4.size(), &d.bvh4)) != RTU_OK) return rc;
         if (need4 > RTU_MAX_BVH_STACK) need4 = RTU_MAX_BVH_STACK;  // a walk that needs more finishes on the reference's tree
         if (need4 > stack_needed) stack_needed = need4;
-        if (getenv("RTU_VERBOSE")) fprintf(stderr, "mesh %u: %u faces, sah depth %u, node4 %zu (stack %u), node8 %zu\n", mi, m.nf, sah.depth, wide4.size() / 8, need4, wide8.size() / 16);
         if (sah.depth > stack_needed) stack_needed = sah.depth;
         if ((rc = upload(ctx, m.f, (size_t)m.nf * 3, &d.f)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;

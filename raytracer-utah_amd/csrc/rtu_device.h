@@ -31,6 +31,7 @@ template <class T> __device__ __forceinline__ const RTU_CONST T* as_const(const 
 // One BVH over a mesh's triangles with its leaf-ordered triangle records.
 struct DevTree {
     const float4*   bvh;        // 2 float4 per node: {bmin.xyz, index} {bmax.xyz, count}; root = node 1; breadth-first
+                                // (nullptr for the fast tree: only its collapsed forms bvh4 / bvh8 are uploaded)
     const float4*   tri;        // 4 float4 per element slot (leaf order), see TriRec in rtu_intersect.h
     const uint32_t* elements;   // element slot -> face id
 };

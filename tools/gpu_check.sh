@@ -1,3 +1,5 @@
+#!/bin/bash
+# On the GPU box (through gpurun): GPU parity suite, GPU-clock timeline (TL_TAGS), bench of the four full-size scenes.
 # quick GPU check: parity suite + timeline + bench of the four full-size scenes
 timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 timeout -k 10 300 python tools/gpu_timeline.py ${TL_TAGS:-teapot2_1080} > gpurun_out/tl.txt 2>&1

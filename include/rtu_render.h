@@ -122,6 +122,17 @@ int  rtu_frame_status(RtuContext* ctx);
 int  rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, int max_entries, int* slot_out,
                          double* start_us_out, double* end_us_out);
 
+/* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
+ * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would
+ * need more is finished on the reference's tree — on any scene. Results must not change. */
+int  rtu_debug_walk_stack_limit(RtuContext* ctx, uint32_t entries);
+
+/* Diagnostic: the acceleration structures built at upload for mesh `mesh`: out5 = {faces, depth of the
+ * binned-SAH tree, deepest stack a walk of its 4-wide form can build (walks are given
+ * min(that, RTU_MAX_BVH_STACK) entries; a ray that needs more finishes on the reference's tree),
+ * 4-wide nodes, 8-wide nodes}. */
+int  rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5);
+
 /* Diagnostic: Shade() frames per recursion level (6 values) and rays deferred to stage 2 per phase
  * (7 values: primary, then levels 0..5) of the most recent frame (fast variant). Synchronises. */
 int  rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out);

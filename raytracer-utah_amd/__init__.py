@@ -113,7 +113,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -128,6 +128,8 @@ _sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
 _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
+_sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
+_sig(hip, "rtu_mesh_info", _I, _P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32))
 _sig(hip, "rtu_frame_counts", _I, _P, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
 _sig(hip, "rtu_render_timeline", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double),
      ctypes.POINTER(ctypes.c_double))
@@ -296,6 +298,12 @@ class Context:
         rows = [(self.TIMELINE_SLOTS[slot[i]], t0[i], t1[i]) for i in range(rc)]
         # launch order: combines run bottom-up after everything else
         return sorted(rows, key=lambda r: (r[0].startswith("k_combine"), -order[r[0]] if r[0].startswith("k_combine") else order[r[0]]))
+
+    def mesh_info(self, mesh=0):
+        """dict(faces, sah_depth, stack4, nodes4, nodes8) of an uploaded mesh."""
+        o = (ctypes.c_uint32 * 5)()
+        self._check(hip.rtu_mesh_info(self._h, mesh, o))
+        return dict(zip(("faces", "sah_depth", "stack4", "nodes4", "nodes8"), list(o)))
 
     def frame_counts(self):
         """(frames per level [6], rays deferred to stage 2 per phase [7]) of the most recent frame."""

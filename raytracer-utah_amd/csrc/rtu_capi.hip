@@ -40,6 +40,8 @@ struct RtuContext {
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
     unsigned long long* counters = nullptr;  // 11 x u64
+    struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
+    std::vector<MeshInfo> mesh_info;
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
     bool stamp_next = false;
 };
@@ -184,6 +186,7 @@ void build_sah(const RtuMesh& m, SahTree& out) {
             }
         }
         uint32_t mid;
+        if (j.level > 28) bestAxis = -1;  // a degenerate distribution must not cost unbounded depth: halve from here on
         if (bestAxis < 0) {
             mid = j.begin + count / 2;  // all centroids coincide: split the list in half
         } else {
@@ -662,6 +665,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     }
 
     // meshes
+    std::vector<RtuContext::MeshInfo> mesh_info;
     std::vector<DevMesh> meshes(s->n_meshes);
     std::vector<uint32_t> fast_nodes(s->n_meshes, 0);
     uint32_t stack_needed = 1;
@@ -717,6 +721,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         uint32_t need4 = 1;
         build_wide4(sah, wide4, need4);
         if ((rc = upload(ctx, wide4.data(), wide4.size(), &d.bvh4)) != RTU_OK) return rc;
+        mesh_info.push_back({m.nf, sah.depth, need4, (uint32_t)(wide4.size() / 8), (uint32_t)(wide8.size() / 16)});
         if (need4 > RTU_MAX_BVH_STACK) need4 = RTU_MAX_BVH_STACK;  // a walk that needs more finishes on the reference's tree
         if (need4 > stack_needed) stack_needed = need4;
         if (sah.depth > stack_needed) stack_needed = sah.depth;
@@ -753,6 +758,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &ds.lights)) != RTU_OK) return rc;
     if ((rc = upload(ctx, meshes.data(), meshes.size(), &ds.meshes)) != RTU_OK) return rc;
     ds.n_nodes = s->n_nodes;
+    ds.walk_stack_limit = 0xFFFFu;
     ds.n_lights = s->n_lights;
     env_value(s->background, ds.background);
     env_value(s->environment, ds.environment);
@@ -762,6 +768,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
     ctx->cap_scale = 1;
     ctx->n_meshes = s->n_meshes;
+    ctx->mesh_info = mesh_info;
     ctx->any_recursive_material = false;
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const RtuMaterial& mm = s->materials[i];
@@ -948,6 +955,19 @@ int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz
         cnt++;
     }
     return cnt;
+}
+
+int rtu_debug_walk_stack_limit(RtuContext* ctx, uint32_t entries) {
+    if (!ctx || entries < 1) return RTU_ERR_ARG;
+    ctx->dscene.walk_stack_limit = entries;
+    return RTU_OK;
+}
+
+int rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5) {
+    if (!ctx || !out5 || mesh >= ctx->mesh_info.size()) return RTU_ERR_ARG;
+    const RtuContext::MeshInfo& i = ctx->mesh_info[mesh];
+    out5[0] = i.faces; out5[1] = i.sah_depth; out5[2] = i.stack4; out5[3] = i.nodes4; out5[4] = i.nodes8;
+    return RTU_OK;
 }
 
 int rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out) {

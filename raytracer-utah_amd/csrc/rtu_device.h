@@ -75,6 +75,7 @@ struct DevScene {
     const RtuLight*    lights;
     const DevMesh*     meshes;
     uint32_t n_nodes, n_lights;
+    uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
     float    environment[3];    // environment.SampleEnvironment(...) likewise
 };

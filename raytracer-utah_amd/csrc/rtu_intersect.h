@@ -517,7 +517,8 @@ __device__ __forceinline__ bool fast_box(const FastRay& f, float4 lo, float4 hi,
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
 template <int STACK, class MeshT>
 __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
-                                               const uint32_t stride, bool& tie) {
+                                               const uint32_t stride, bool& tie, const uint32_t stackLimit) {
+    const int slim = (int)(stackLimit < (uint32_t)STACK ? stackLimit : (uint32_t)STACK);
     // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches.
     const float4* bvh4 = mesh.bvh4;
     const float4* tris = mesh.fast.tri;
@@ -553,7 +554,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
             uint32_t next;
             if (kbest < inf) {
                 const int n = (int)(kx < inf) + (int)(ky < inf) + (int)(kz < inf) + (int)(kw < inf);
-                if (sp + n - 1 > STACK) {  // would not fit: finish on the reference's tree
+                if (sp + n - 1 > slim) {  // would not fit: finish on the reference's tree
                     tie = true;
                     alive = false;
                     next = 1u << 28;
@@ -609,13 +610,13 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
 // falls back to the reference's on an exact tie (see DevMesh).
 template <int STACK, bool STATS, bool CULL>
 __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
-                                         const uint32_t stride = 64) {
+                                         const uint32_t stackLimit, const uint32_t stride = 64) {
     if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
     RTU_CNT(mesh);
     bool tie = false;
     if (!CULL) return mesh_walk<STACK, STATS, false, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, tie);
     const Hit h0 = h;
-    bool r = mesh_walk_fast<STACK>(mesh, ray, shadow, h, stk, cnt, stride, tie);
+    bool r = mesh_walk_fast<STACK>(mesh, ray, shadow, h, stk, cnt, stride, tie, stackLimit);
     if (tie) {  // rare: two accepted triangles with bitwise-equal t — the reference's test order decides
         h = h0;
         bool t2 = false;
@@ -651,7 +652,8 @@ __device__ __forceinline__ int grp_xor(int v) {  // value of lane ^ M
 // The caller has established that the ray passes the mesh's bounding box.
 template <int STACK, bool CULL, class MeshT>
 __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
-                                              const uint32_t stride, const float4* lds_nodes) {
+                                              const uint32_t stride, const float4* lds_nodes, const uint32_t stackLimit) {
+    const uint32_t slim = stackLimit < (uint32_t)RTU_STACK8 ? stackLimit : (uint32_t)RTU_STACK8;
     const Hit h0 = h;
     bool tie = false;
     const float4* bvh8 = mesh.bvh8;
@@ -686,7 +688,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
                 }
             } else {
                 const uint32_t n = (uint32_t)__popc(m8);
-                if (sp + n > (uint32_t)RTU_STACK8) {  // would not fit (group-uniform): finish on the reference's tree
+                if (sp + n > slim) {  // would not fit (group-uniform): finish on the reference's tree
                     tie = true;
                     alive = false;
                     next = 1u << 28;
@@ -831,8 +833,13 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
             const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
             if (box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) deferred = true;
             hit = false;
-        } else if (COOP) hit = mesh_hit_coop<STACK, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, stride, lds_nodes);
-        else hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt);
+        } else if (COOP) {
+            const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
+            hit = box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT) &&  // TriObj::IntersectRay's own box test (:335)
+                  mesh_hit_coop<STACK, CULL>(mesh, lr, shadow, h, stk, cnt, stride, lds_nodes, s.walk_stack_limit);
+        } else {
+            hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, s.walk_stack_limit);
+        }
         if (hit) {
             any = true;
             best = (int)k;  // h.p / h.N are in node k's space

@@ -199,6 +199,61 @@ def test_exact_ties_follow_the_reference_order(pkg, orc, ctx, tmp_path):
     assert gst["primary_hits"] > 1000
 
 
+def test_degenerate_mesh_deep_trees(pkg, orc, ctx, tmp_path):
+    """300 triangles in geometric progression: the reference's mean-split BVH is 42 levels deep (its
+    walk needs most of the 48 stack entries); the SAH tree stays shallow. Must be the reference's image."""
+    verts, faces = [], []
+    x = 1e-3
+    for i in range(300):
+        sz = x * 0.4
+        y = ((i * 37) % 11 - 5) * sz * 0.3
+        base = len(verts)
+        verts += [(x, y, 0.0), (x + sz, y, 0.01 * sz), (x, y + sz, 0.0)]
+        faces.append((base + 1, base + 2, base + 3))
+        x *= 1.05
+    obj = tmp_path / "geo.obj"
+    with open(obj, "w") as f:
+        for v in verts: f.write("v %r %r %r\n" % v)
+        f.write("vn 0 0 1\n")
+        for (i, j, k) in faces: f.write("f %d//1 %d//1 %d//1\n" % (i, j, k))
+    xml = tmp_path / "geo.xml"
+    xml.write_text("""<xml><scene>
+      <object type="obj" name="%s" material="m"/>
+      <material type="blinn" name="m"><diffuse r="0.8" g="0.5" b="0.2"/><specular value="0.5"/><reflection value="0.3"/></material>
+      <light type="direct" name="d"><intensity value="1"/><direction x="-0.3" y="0.2" z="-1"/></light>
+      <light type="ambient" name="a"><intensity value="0.1"/></light>
+    </scene><camera><position x="%r" y="0" z="%r"/><target x="%r" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="50"/>
+      <width value="160"/><height value="120"/></camera></xml>""" % (obj, x * 0.3, x * 0.5, x * 0.3))
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 160, 120
+    fast, _ = render_gpu(pkg, ctx, scene, W, H, stats=False)
+    info = ctx.mesh_info(0)
+    assert info["faces"] == 300 and info["sah_depth"] <= 32, info
+    cnt, gst = render_gpu(pkg, ctx, scene, W, H, stats=True)
+    cpu, cst = orc.render(scene, W, H, threads=2)
+    assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32))
+    check_against(fast, cpu, orc)
+    assert gst == cst
+    assert gst["primary_hits"] > 500
+
+
+@pytest.mark.parametrize("tag,coop", [("teapot2_240x135", True), ("teapot2_240x135", False), ("p11_240x135", False)])
+def test_walk_stack_overflow_falls_back_to_the_reference_tree(pkg, ctx, golden, tag, coop):
+    """A walk of the 4-wide / 8-wide tree that would need more stack than it has finishes on the
+    reference's tree (like an exact tie). Forced here by a test hook that leaves the walks 3
+    entries: the frame must not change in any bit, on the cooperative and the wide kernels."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    fr = pkg.frame_setup(scene.desc.camera, g.width, g.height)
+    fr.coop_threshold = 10 ** 9 if coop else 1
+    ref, _ = ctx.render(fr)
+    assert pkg.hip.rtu_debug_walk_stack_limit(ctx._h, 3) == 0
+    small, _ = ctx.render(fr)
+    assert np.array_equal(ref.view(np.uint32), small.view(np.uint32))
+    ctx.upload(scene)  # restores the limit
+
+
 def test_exact_division(pkg, ctx):
     """(float)((double)n * (1.0/(double)d)) == n / d bit for bit (rtu_intersect.h fdiv): 2^31
     pseudo-random operand pairs incl. subnormals, zeros, infinities, NaNs, near-1 quotients."""

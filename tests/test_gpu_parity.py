@@ -237,6 +237,90 @@ def test_degenerate_mesh_deep_trees(pkg, orc, ctx, tmp_path):
     assert gst["primary_hits"] > 500
 
 
+def _write_uv_mesh(path, nu, nv, fn):
+    """OBJ of a parametric surface fn(u, v) -> (x, y, z), smooth normals by finite differences."""
+    import math
+    verts, norms, faces = [], [], []
+    for i in range(nu + 1):
+        for j in range(nv + 1):
+            u, v = i / nu, j / nv
+            p = fn(u, v)
+            du = [a - b for a, b in zip(fn(u + 1e-4, v), fn(u - 1e-4, v))]
+            dv = [a - b for a, b in zip(fn(u, v + 1e-4), fn(u, v - 1e-4))]
+            n = (du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0])
+            ln = math.sqrt(sum(c * c for c in n)) or 1.0
+            verts.append(p)
+            norms.append(tuple(c / ln for c in n))
+    for i in range(nu):
+        for j in range(nv):
+            a = i * (nv + 1) + j + 1
+            b, c, d = a + 1, a + nv + 1, a + nv + 2
+            faces += [(a, c, b), (b, c, d)]
+    with open(path, "w") as f:
+        for v in verts: f.write("v %r %r %r\n" % tuple(v))
+        for n in norms: f.write("vn %r %r %r\n" % n)
+        for (i, j, k) in faces: f.write("f %d//%d %d//%d %d//%d\n" % (i, i, j, j, k, k))
+    return len(faces)
+
+
+@pytest.mark.parametrize("coop", [True, False])
+def test_two_meshes_nested_transforms_glass_and_mirror(pkg, orc, ctx, tmp_path, coop):
+    """A scene none of the reference's files has: two DIFFERENT meshes (one instanced twice) under
+    three levels of rotated / non-uniformly scaled groups, a glass sphere in front of them, a
+    mirror floor, a point and a direct light. GPU (both kernel variants, cooperative or wide stage 2)
+    against the CPU oracle: z bit-exact, RGB within the bar, all counters equal."""
+    import math
+    def torus(u, v):
+        a, b = 2 * math.pi * u, 2 * math.pi * v
+        return ((2 + 0.7 * math.cos(b)) * math.cos(a), (2 + 0.7 * math.cos(b)) * math.sin(a), 0.7 * math.sin(b))
+    def blob(u, v):
+        a, b = 2 * math.pi * u, math.pi * (v - 0.5)
+        r = 1.5 + 0.3 * math.sin(5 * a) * math.cos(3 * b)
+        return (r * math.cos(b) * math.cos(a), r * math.cos(b) * math.sin(a), r * math.sin(b))
+    n1 = _write_uv_mesh(tmp_path / "torus.obj", 40, 16, torus)
+    n2 = _write_uv_mesh(tmp_path / "blob.obj", 36, 18, blob)
+    assert n1 == 1280 and n2 == 1296
+    xml = tmp_path / "two.xml"
+    xml.write_text("""<xml><scene>
+      <object type="plane" name="floor" material="mirror"><scale value="40"/><translate z="-4"/></object>
+      <object name="g1"><rotate angle="20" z="1"/><translate x="1" y="2" z="0"/>
+        <object type="obj" name="{d}/torus.obj" material="red"><scale x="1.2" y="0.8" z="1.5"/><rotate angle="35" x="1"/></object>
+        <object name="g2"><scale value="0.7"/><rotate angle="-40" y="1"/><translate x="-5" y="1" z="1"/>
+          <object type="obj" name="{d}/blob.obj" material="green"><rotate angle="15" x="1"/></object>
+          <object name="g3"><translate x="0" y="-5" z="2"/><rotate angle="70" z="1"/>
+            <object type="obj" name="{d}/torus.obj" material="glossy"><scale value="0.6"/></object>
+            <object type="sphere" name="s_in" material="green"><scale value="0.5"/><translate z="2"/></object>
+          </object>
+        </object>
+      </object>
+      <object type="sphere" name="glass" material="glass"><scale x="2.2" y="2.2" z="2.6"/><translate x="2" y="-7" z="1"/></object>
+      <material type="blinn" name="red"><diffuse r="0.8" g="0.2" b="0.2"/><specular value="0.6"/><glossiness value="40"/></material>
+      <material type="blinn" name="green"><diffuse r="0.2" g="0.7" b="0.3"/><specular value="0.3"/><glossiness value="10"/></material>
+      <material type="blinn" name="glossy"><diffuse r="0.5" g="0.5" b="0.6"/><specular value="0.8"/><glossiness value="80"/><reflection value="0.4"/></material>
+      <material type="blinn" name="mirror"><diffuse r="0.2" g="0.2" b="0.2"/><specular value="0.7"/><glossiness value="30"/><reflection value="0.6"/></material>
+      <material type="blinn" name="glass"><diffuse r="0.05" g="0.05" b="0.05"/><specular value="0.9"/><glossiness value="100"/>
+        <refraction index="1.5" value="0.9"/><absorption r="0.02" g="0.01" b="0.03"/></material>
+      <light type="ambient" name="a"><intensity value="0.15"/></light>
+      <light type="direct" name="d"><intensity value="0.5"/><direction x="0.4" y="0.6" z="-1"/></light>
+      <light type="point" name="p"><intensity value="0.6"/><position x="-6" y="-12" z="14"/></light>
+    </scene><camera><position x="3" y="-24" z="9"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="38"/>
+      <width value="256"/><height value="160"/></camera></xml>""".format(d=tmp_path))
+    scene = pkg.Scene.from_xml(str(xml))
+    assert scene.desc.n_meshes == 2
+    W, H = 256, 160
+    ctx.upload(scene)
+    fr = pkg.frame_setup(scene.desc.camera, W, H)
+    fr.coop_threshold = 10 ** 9 if coop else 1
+    fast, _ = ctx.render(fr)
+    frs = pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True)
+    cnt, gst = ctx.render(frs, stats=True)
+    cpu, cst = orc.render(scene, W, H, threads=4)
+    assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast and counting variants differ"
+    check_against(fast, cpu, orc)
+    assert gst == cst
+    assert gst["secondary_rays"] > 5000 and gst["mesh_entries"] > 10000
+
+
 @pytest.mark.parametrize("tag,coop", [("teapot2_240x135", True), ("teapot2_240x135", False), ("p11_240x135", False)])
 def test_walk_stack_overflow_falls_back_to_the_reference_tree(pkg, ctx, golden, tag, coop):
     """A walk of the 4-wide / 8-wide tree that would need more stack than it has finishes on the

@@ -14,13 +14,16 @@ def gather_framebuffer(shard, gathered, dist):
 
 class FramePipeline:
     """Double-buffered frame loop of one rank: frame i is rendered into shard buffer i % 2 and its
-    all_gather is issued asynchronously, so the collective (RCCL's own stream) overlaps the kernels
-    of frame i+1, which write the other buffer. begin(i) makes the current stream wait for the
-    gather that last read buffer i % 2 (frame i-2); drain() waits for everything in flight.
-    staged=True (rehearsal on gloo): the collective runs on host copies of the buffers."""
+    gather TO RANK 0 (every GPU writes its 1/N of the frame to the root over its own
+    xGMI link — grouped send/recv in RCCL, not a ring) is issued asynchronously, so the transfer
+    overlaps the kernels of frame i+1, which write the other buffer. begin(i) makes the current
+    stream wait for the gather that last read buffer i % 2 (frame i-2); drain() waits for everything
+    in flight. gathers[b] exists on rank 0 only ([world, n]); root_only=False falls back to
+    all_gather (every rank receives the frame). staged=True (rehearsal on gloo): host copies."""
 
-    def __init__(self, shards, gathers, dist, staged=False):
-        self.shards, self.gathers, self.dist, self.staged = shards, gathers, dist, staged
+    def __init__(self, shards, gathers, dist, staged=False, root_only=True):
+        self.shards, self.gathers, self.dist, self.staged, self.root_only = shards, gathers, dist, staged, root_only
+        self.rank = dist.get_rank()
         self.work = [None, None]
         self.last = None
 
@@ -34,7 +37,11 @@ class FramePipeline:
     def gather(self, i):
         b = i & 1
         src = self.shards[b].cpu() if self.staged else self.shards[b]
-        self.work[b] = self.dist.all_gather_into_tensor(self.gathers[b], src, async_op=True)
+        if self.root_only:
+            dst = list(self.gathers[b].unbind(0)) if self.rank == 0 else None
+            self.work[b] = self.dist.gather(src, gather_list=dst, dst=0, async_op=True)
+        else:
+            self.work[b] = self.dist.all_gather_into_tensor(self.gathers[b].view(-1), src, async_op=True)
         self.last = b
 
     def drain(self):
@@ -44,7 +51,8 @@ class FramePipeline:
                 self.work[b] = None
 
     def last_gathered(self):
-        return self.gathers[self.last]
+        """[world, n] on rank 0 (on every rank with root_only=False)."""
+        return self.gathers[self.last] if self.gathers is not None else None
 
 
 def assemble_gathered(pkg, gathered_np, camera, width, height, world):

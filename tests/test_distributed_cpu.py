@@ -45,17 +45,23 @@ def _worker(rank, world, port, tag, out_dir):
     gathered = torch.empty(world * max_rows * W * 4, dtype=torch.float32)
     sharding.gather_framebuffer(shard, gathered, dist)
     # the double-buffered loop of bench.py: three frames (the third reuses buffer 0), every gather identical
-    shards = [shard.clone(), shard.clone()]
-    gathers = [torch.empty_like(gathered), torch.empty_like(gathered)]
-    pipe = sharding.FramePipeline(shards, gathers, dist)
-    for i in range(3):
-        b = pipe.begin(i)
-        assert b is shards[i & 1]
-        b.copy_(shard)  # "render"
-        pipe.gather(i)
-    pipe.drain()
-    assert pipe.last_gathered() is gathers[0]
-    assert torch.equal(gathers[0], gathered) and torch.equal(gathers[1], gathered)
+    for root_only in (True, False):
+        shards = [shard.clone(), shard.clone()]
+        gathers = None
+        if rank == 0 or not root_only:
+            gathers = [torch.empty(world, max_rows * W * 4), torch.empty(world, max_rows * W * 4)]
+        pipe = sharding.FramePipeline(shards, gathers, dist, root_only=root_only)
+        for i in range(3):
+            b = pipe.begin(i)
+            assert b is shards[i & 1]
+            b.copy_(shard)  # "render"
+            pipe.gather(i)
+        pipe.drain()
+        if gathers is not None:
+            assert pipe.last_gathered() is gathers[0]
+            assert torch.equal(gathers[0].view(-1), gathered) and torch.equal(gathers[1].view(-1), gathered)
+        else:
+            assert pipe.last_gathered() is None
     lo, hi = sharding.global_minmax_z(shard.view(max_rows, W, 4)[:len(rows), :, 3], dist, torch)
     img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).numpy(), scene.desc.camera, W, H, world)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)

@@ -122,6 +122,12 @@ int  rtu_frame_status(RtuContext* ctx);
 int  rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, int max_entries, int* slot_out,
                          double* start_us_out, double* end_us_out);
 
+/* Diagnostic, after rtu_render_timeline: the exit times (microseconds after the kernel's first entry) of
+ * the wavefronts of the launch in timeline slot `slot` — one value per wavefront slot (index modulo
+ * 8192; a later wavefront overwrites an earlier one). Shows whether a launch is a plateau or a tail.
+ * Returns the number of values written. */
+int  rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_us_out);
+
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
  * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would
  * need more is finished on the reference's tree — on any scene. Results must not change. */

@@ -113,7 +113,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -129,6 +129,7 @@ _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
+_sig(hip, "rtu_timeline_exits", _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double))
 _sig(hip, "rtu_mesh_info", _I, _P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32))
 _sig(hip, "rtu_frame_counts", _I, _P, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
 _sig(hip, "rtu_render_timeline", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double),
@@ -298,6 +299,16 @@ class Context:
         rows = [(self.TIMELINE_SLOTS[slot[i]], t0[i], t1[i]) for i in range(rc)]
         # launch order: combines run bottom-up after everything else
         return sorted(rows, key=lambda r: (r[0].startswith("k_combine"), -order[r[0]] if r[0].startswith("k_combine") else order[r[0]]))
+
+    def timeline_exits(self, kernel):
+        """Exit times (us after the kernel's first entry) of the wavefronts of `kernel` (a name of
+        TIMELINE_SLOTS) in the frame last rendered by render_timeline."""
+        import numpy as np
+        buf = (ctypes.c_double * 8192)()
+        rc = hip.rtu_timeline_exits(self._h, self.TIMELINE_SLOTS.index(kernel), 8192, buf)
+        if rc < 0:
+            self._check(rc)
+        return np.array(buf[:rc])
 
     def mesh_info(self, mesh=0):
         """dict(faces, sah_depth, stack4, nodes4, nodes8) of an uploaded mesh."""

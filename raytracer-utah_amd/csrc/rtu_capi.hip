@@ -957,6 +957,24 @@ int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz
     return cnt;
 }
 
+int rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_us_out) {
+    if (!ctx || !exit_us_out || slot < 0 || slot >= RTU_TL_KERNELS || max_values < 1) return RTU_ERR_ARG;
+    if (!ctx->tl) return fail(ctx, RTU_ERR_ARG, "no timeline recorded yet (rtu_render_timeline)");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<unsigned long long> h(RTU_TL_STRIDE);
+    RTU_HIP(ctx, hipMemcpy(h.data(), ctx->tl + (size_t)slot * RTU_TL_STRIDE, RTU_TL_STRIDE * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int khz = 0;
+    RTU_HIP(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (khz <= 0) khz = 100000;
+    unsigned long long t0 = ~0ull;
+    for (uint32_t j = 0; j < 64; j++) if (h[j] && h[j] < t0) t0 = h[j];
+    if (t0 == ~0ull) return 0;
+    int n = 0;
+    for (uint32_t j = 64; j < RTU_TL_STRIDE && n < max_values; j++)
+        if (h[j]) exit_us_out[n++] = (double)(h[j] - t0) * 1e3 / (double)khz;
+    return n;
+}
+
 int rtu_debug_walk_stack_limit(RtuContext* ctx, uint32_t entries) {
     if (!ctx || entries < 1) return RTU_ERR_ARG;
     ctx->dscene.walk_stack_limit = entries;

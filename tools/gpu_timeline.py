@@ -27,5 +27,14 @@ for tag in sys.argv[1:] or ["teapot2_1080"]:
         print("  %-18s start %8.1f  end %8.1f  dur %7.1f  gap %6.1f" % (name, t0, t1, t1 - t0, t0 - prev_end))
         prev_end = max(prev_end, t1)
     print("  frame span %.1f us" % prev_end)
+    if os.environ.get("TL_EXITS"):
+        import numpy as np
+        for name, t0, t1 in rows:
+            if t1 - t0 < 10:
+                continue
+            e = ctx.timeline_exits(name)
+            if len(e):
+                q = np.percentile(e, [10, 50, 90, 99])
+                print("    %-16s wavefront exits: n=%d p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (name, len(e), q[0], q[1], q[2], q[3], e.max()))
     pkg.hip.rtu_device_free(ctx._h, d)
 ctx.close()

@@ -607,8 +607,12 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
                 st[k] = RTU_CH_MISS;
             }
         }
+        const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
+        {  // frames that wait for children go on the shard's list for k_combine (never more than frames)
+            const uint32_t pi = wave_append(&a.fcnt->n_pending[L][shard], pending);
+            if (pending) lv.fpend[(size_t)shard * lv.cap_s + pi] = fl;
+        }
         if (!active) continue;
-        const bool pending = st[0] >= 0 || st[1] >= 0 || st[2] >= 0;
         if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
         if (!pending) {
             const f3 one = mk3(1, 1, 1);
@@ -627,18 +631,22 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
-    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
-    const uint32_t chunks = kmax * RTU_SHARDS;
+    // only the frames k_consume listed as waiting for children
+    uint32_t pmax = a.fcnt->n_pending[L][lane_id() % RTU_SHARDS];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)pmax, off);
+        pmax = o > pmax ? o : pmax;
+    }
+    const uint32_t chunks = ((pmax + 63u) / 64u) * RTU_SHARDS;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        const uint32_t fl = k * 64u + threadIdx.x;
-        if (fl >= shard_count(a, L, shard)) continue;
-        const uint32_t f = shard * lv.cap_s + fl;
+        const uint32_t e = k * 64u + threadIdx.x;
+        if (e >= a.fcnt->n_pending[L][shard]) continue;
+        const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
         const float4 fa = lv.fa[f];
         const uint32_t info = __float_as_uint(fa.w);
-        if (!(info & (RTU_FI_MAIN | RTU_FI_C))) continue;  // never had secondary rays
         const int4 ch = lv.fchild[f];
-        if (!ch.w) continue;                                // already final
         const float4 fb = lv.fb[f], fc = lv.fc[f], fr = lv.fres[f];
         const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
         const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];

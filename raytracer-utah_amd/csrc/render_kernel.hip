@@ -127,6 +127,22 @@ __device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bo
     return info;
 }
 
+// A new frame of level L (index fl within its shard) joins the lists of the frames that fire
+// secondary rays, so that k_trace visits the secondary slots only where there is a ray.
+// Wave-uniform: must be reached by all 64 lanes.
+__device__ __forceinline__ void list_frame(const KernelArgs& a, int L, uint32_t shard, bool made, uint32_t info, uint32_t fl) {
+    const LevelBuffers& lv = a.lv[L];
+    const bool m = made && (info & RTU_FI_MAIN), c = made && (info & RTU_FI_C);
+    if (__any(m)) {
+        const uint32_t i = wave_append(&a.fcnt->n_lmain[L][shard], m);
+        if (m) lv.lmain[(size_t)shard * lv.cap_s + i] = fl;
+    }
+    if (__any(c)) {
+        const uint32_t i = wave_append(&a.fcnt->n_lrefl[L][shard], c);
+        if (c) lv.lrefl[(size_t)shard * lv.cap_s + i] = fl;
+    }
+}
+
 __device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Init, scene.h:162
     h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
 }
@@ -217,19 +233,23 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             }
         }
     }
-    uint32_t idx = wave_append(&a.fcnt->n_frames[0][shard], want);
+    const uint32_t fl = wave_append(&a.fcnt->n_frames[0][shard], want);
+    uint32_t info = 0;
+    bool made = false;
     if (want) {
         const LevelBuffers& lv = a.lv[0];
-        if (idx < lv.cap_s) {
-            idx += shard * lv.cap_s;
-            uint32_t info = make_info(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N);
+        if (fl < lv.cap_s) {
+            const uint32_t idx = fl + shard * lv.cap_s;
+            info = make_info(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N);
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
             lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
+            made = true;
         } else {
             a.fcnt->overflow = 1;
         }
     }
+    list_frame(a, 0, shard, made, info, fl);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
@@ -400,17 +420,44 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
-    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;  // 64-frame chunks per shard
-    const uint32_t chunks = kmax * RTU_SHARDS;                  // per slot
-    const uint32_t nslots = a.nsl + 3u;
-    const uint32_t total = chunks * nslots;
+    // shadow slots: every frame of the level; secondary slots: the frames listed for them (list_frame)
+    uint32_t vm = a.fcnt->n_lmain[L][lane % RTU_SHARDS], vc = a.fcnt->n_lrefl[L][lane % RTU_SHARDS];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)vm, off);
+        vm = o > vm ? o : vm;
+        o = (uint32_t)__shfl_xor((int)vc, off);
+        vc = o > vc ? o : vc;
+    }
+    const uint32_t chA = ((level_max_count(a, L) + 63u) / 64u) * RTU_SHARDS;  // 64-frame chunks, all shards
+    const uint32_t chM = ((vm + 63u) / 64u) * RTU_SHARDS, chC = ((vc + 63u) / 64u) * RTU_SHARDS;
+    const uint32_t total = a.nsl * chA + 2u * chM + chC;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
-        const uint32_t slot = c / chunks;
-        const uint32_t cc = c - slot * chunks;
+        uint32_t slot, cc;
+        const uint32_t* list = nullptr;
+        const uint32_t* counts = a.fcnt->n_frames[L];
+        if (c < a.nsl * chA) {
+            slot = c / chA;
+            cc = c - slot * chA;
+        } else if (c - a.nsl * chA < 2u * chM) {
+            const uint32_t c2 = c - a.nsl * chA;
+            slot = a.nsl + (c2 >= chM ? (uint32_t)SLOT_A : (uint32_t)SLOT_MAIN);
+            cc = c2 >= chM ? c2 - chM : c2;
+            list = lv.lmain;
+            counts = a.fcnt->n_lmain[L];
+        } else {
+            slot = a.nsl + (uint32_t)SLOT_C;
+            cc = c - a.nsl * chA - 2u * chM;
+            list = lv.lrefl;
+            counts = a.fcnt->n_lrefl[L];
+        }
         const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
-        const uint32_t fl = k * 64u + lane;
-        const bool active = fl < shard_count(a, L, shard);
+        const uint32_t e = k * 64u + lane;
+        uint32_t ns = counts[shard];
+        if (ns > lv.cap_s) ns = lv.cap_s;
+        const bool active = e < ns;
+        const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
         const uint32_t f = shard * lv.cap_s + fl;
         bool deferred = false;
         if (active) deferred = frame_ray<STACK, STATS, !STATS>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
@@ -588,24 +635,29 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
             const bool spawn = hit && cmid >= 0 && haveNext;
             if (k == SLOT_MAIN && hit) { bz = s0.w; bfront = (packed & 2u) != 0; }
             const uint32_t cshard = c % RTU_SHARDS;
-            uint32_t idx = wave_append(&a.fcnt->n_frames[Ln][cshard], spawn);  // all 64 lanes take part
-            if (!slotActive) continue;
-            if (!hit) st[k] = RTU_CH_MISS;
-            else if (cmid < 0) st[k] = RTU_CH_WHITE;
-            else if (spawn && idx < nx.cap_s) {
-                idx += cshard * nx.cap_s;
-                // the child Shade(): ray direction, hit point and normal of the secondary ray
-                const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
-                const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
-                const uint32_t cinfo = make_info(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN);
-                nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-                nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
-                nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0.w);
-                st[k] = (int)idx;
-            } else {
-                a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
-                st[k] = RTU_CH_MISS;
+            const uint32_t cfl = wave_append(&a.fcnt->n_frames[Ln][cshard], spawn);  // all 64 lanes take part
+            uint32_t cinfo = 0;
+            bool made = false;
+            if (slotActive) {
+                if (!hit) st[k] = RTU_CH_MISS;
+                else if (cmid < 0) st[k] = RTU_CH_WHITE;
+                else if (spawn && cfl < nx.cap_s) {
+                    const uint32_t idx = cfl + cshard * nx.cap_s;
+                    // the child Shade(): ray direction, hit point and normal of the secondary ray
+                    const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
+                    const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
+                    cinfo = make_info(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN);
+                    nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
+                    nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
+                    nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0.w);
+                    st[k] = (int)idx;
+                    made = true;
+                } else {
+                    a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
+                    st[k] = RTU_CH_MISS;
+                }
             }
+            if (haveNext) list_frame(a, Ln, cshard, made, cinfo, cfl);
         }
         const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
         {  // frames that wait for children go on the shard's list for k_combine (never more than frames)

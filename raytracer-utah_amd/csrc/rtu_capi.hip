@@ -520,6 +520,8 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
         if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fpend, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.lmain, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.lrefl, cap)) != RTU_OK) return rc;
         lv.cap_s = (uint32_t)cap_s;
     }
     // defer list: at most every ray of the largest phase (all slots of the largest level)

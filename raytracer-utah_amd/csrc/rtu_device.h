@@ -113,6 +113,8 @@ struct LevelBuffers {
     int4*   fchild;  // {main child, Fresnel child, mirror child, pending}
     float*  fsh;     // [cap * nsl] Shadow() of every non-ambient light
     float4* fslot;   // [cap * 3 * 2] closest hit of the three secondary rays: {p.xyz,z} {N.xyz,packed}
+    uint32_t* lmain; // [cap] per shard: the frames (index within the shard) that fire a refracted / TIR (and Fresnel) ray
+    uint32_t* lrefl; // [cap] per shard: the frames that fire a mirror ray — k_trace visits these lists for the secondary slots
     uint32_t* fpend; // [cap] per shard: the frames (index within the shard) that wait for children — what k_combine visits
     uint32_t cap_s;  // capacity of ONE shard; frame id = shard * cap_s + index within the shard
     uint32_t pad;
@@ -141,6 +143,8 @@ struct FrameCounters {
     uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS];
     uint32_t n_defer[RTU_MAX_LEVELS + 1][RTU_SHARDS];  // phase 0 = primary rays, phase 1+L = rays of level L
     uint32_t n_pending[RTU_MAX_LEVELS][RTU_SHARDS];    // frames waiting for children (fpend)
+    uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS];      // entries of lmain / lrefl
+    uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS];
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more
     uint32_t pad[3];
 };

@@ -808,7 +808,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     const dim3 block(64);
     // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
     // workgroups, so the deeper, usually sparse levels get smaller grids
-    const dim3 gridT(8192), gridN(16384), gridS(8192), gridF(2048), gridC(1024), gridCoop(512);
+    const dim3 gridT(8192), gridN(8192), gridS(8192), gridF(2048), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
     if (stats) {

@@ -14,7 +14,7 @@ for tag in sys.argv[1:] or ["teapot2_1080"]:
     W, H = meta["width"], meta["height"]
     scene = pkg.Scene.from_blob_file(os.path.join(gdir, "scene.rtus.gz"))
     ctx.upload(scene)
-    fr = pkg.frame_setup(scene.desc.camera, W, H)
+    fr = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=0, shard_count=int(os.environ.get("TL_SHARDS", "1")))
     d = pkg.hip.rtu_device_alloc(ctx._h, W * H * 16)
     for _ in range(3):
         rows = ctx.render_timeline(fr, d)

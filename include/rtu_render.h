@@ -109,8 +109,10 @@ int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz,
 
 /* After rtu_render_frame_device: wait for the device and report whether the frame is
  * complete. The Shade() recursion is evaluated level by level in pre-sized frame
- * arrays; RTU_ERR_CAPACITY means a level overflowed (the arrays are doubled, render the
- * frame again). rtu_render_frame does this check and the re-render itself. */
+ * arrays (one frame per pixel per level to begin with); RTU_ERR_CAPACITY means a level
+ * overflowed: the arrays are re-provisioned from the counts the frame reported — render the
+ * frame again (at most one round per recursion level). rtu_render_frame does the check and
+ * the re-render itself. */
 int  rtu_frame_status(RtuContext* ctx);
 
 /* Diagnostic: render one frame with every wavefront stamping the GPU's constant clock on entry

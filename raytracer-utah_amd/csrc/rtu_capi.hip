@@ -29,7 +29,8 @@ struct RtuContext {
     LevelBuffers lv[RTU_MAX_LEVELS] = {};
     uint32_t level_cap0 = 0;        // pixels the level buffers were sized for
     uint32_t level_nsl = 0;
-    uint32_t cap_scale = 1;         // capacity of levels >= 1 = cap_scale * pixels (doubled on overflow)
+    uint32_t want_cap_s[RTU_MAX_LEVELS] = {};  // per-shard capacity wanted for levels >= 1 (grown from the counts of an overflowed frame)
+    uint32_t want_defer_s = 0;
     FrameCounters* fcnt = nullptr;
     uint32_t* defer_list = nullptr;
     uint32_t  defer_cap_s = 0;
@@ -498,20 +499,36 @@ int alloc_level(RtuContext* ctx, T** dst, size_t count) {
     return RTU_OK;
 }
 
-// Frame arrays of every recursion level (rtu_device.h). Level 0 holds at most one
-// frame per pixel; deeper levels get cap_scale * pixels and are grown on overflow.
+// Frame arrays of every recursion level (rtu_device.h). Level 0 holds at most one frame per
+// pixel; a deeper level starts with the same capacity and is grown to what an overflowed frame
+// reported (check_overflow) — a frame can hold up to 3^L frames per pixel at level L in theory,
+// a tenth of a frame per pixel in the reference's scenes.
 int ensure_levels(RtuContext* ctx, uint32_t pixels) {
     // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile
     size_t tiles = ((size_t)pixels + 63) / 64 + 8;  // +8: ragged right/bottom tiles
     size_t cap_s0 = ((tiles + RTU_SHARDS - 1) / RTU_SHARDS) * 64;
-    if (ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && ctx->lv[1].cap_s >= ctx->cap_scale * cap_s0) return RTU_OK;
+    size_t want[RTU_MAX_LEVELS];
+    size_t maxcap = cap_s0;
+    bool fits = ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl;
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        want[L] = L == 0 || ctx->want_cap_s[L] < cap_s0 ? cap_s0 : ctx->want_cap_s[L];
+        if (want[L] > maxcap) maxcap = want[L];
+        fits = fits && ctx->lv[L].cap_s >= want[L];
+    }
+    // defer list: at most every ray of the largest phase (all slots of the largest level)
+    size_t dcap_s = maxcap * (ctx->nsl + 3);
+    if (ctx->want_defer_s > dcap_s) dcap_s = ctx->want_defer_s;
+    if (fits && ctx->defer_cap_s >= dcap_s) return RTU_OK;
     free_levels(ctx);
     int rc;
+    size_t total = 0;
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) total += want[L] * RTU_SHARDS * (size_t)(16 * 11 + 4 * (ctx->nsl ? ctx->nsl : 1) + 12);
+    if (total > ((size_t)96 << 30)) return fail(ctx, RTU_ERR_CAPACITY, "the recursion of this frame needs %zu GB of frame records", total >> 30);
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         LevelBuffers& lv = ctx->lv[L];
-        size_t cap_s = L == 0 ? cap_s0 : cap_s0 * ctx->cap_scale;
+        size_t cap_s = want[L];
         size_t cap = cap_s * RTU_SHARDS;
-        if (cap > 0x7FFFFFF0u) return fail(ctx, RTU_ERR_UNSUPPORTED, "frame capacity overflow");
+        if (cap > 0x0FFFFFF0u) return fail(ctx, RTU_ERR_CAPACITY, "more than 2^28 frames in one recursion level");
         if ((rc = alloc_level(ctx, &lv.fa, cap)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fb, cap)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fc, cap)) != RTU_OK) return rc;
@@ -524,8 +541,6 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
         if ((rc = alloc_level(ctx, &lv.lrefl, cap)) != RTU_OK) return rc;
         lv.cap_s = (uint32_t)cap_s;
     }
-    // defer list: at most every ray of the largest phase (all slots of the largest level)
-    size_t dcap_s = (size_t)ctx->lv[1].cap_s * (ctx->nsl + 3);
     if ((rc = alloc_level(ctx, &ctx->defer_list, dcap_s * RTU_SHARDS)) != RTU_OK) return rc;
     ctx->defer_cap_s = (uint32_t)dcap_s;
     ctx->level_cap0 = pixels;
@@ -565,10 +580,36 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 }
 
 // After the stream has drained: did any recursion level run out of frame capacity?
+// The append counters keep counting past the capacity, so an overflowed frame tells how much its
+// first overflowing level really needs (deeper levels may need another round: their parents were
+// dropped). Wanted capacities grow to the reported counts (+25 %, at least x2 for the level below).
 int check_overflow(RtuContext* ctx, bool* overflow) {
     FrameCounters h;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     *overflow = h.overflow != 0;
+    if (!*overflow) return RTU_OK;
+    bool grew = false;
+    for (int L = 1; L < RTU_MAX_LEVELS; L++) {
+        uint32_t need = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) need = h.n_frames[L][s] > need ? h.n_frames[L][s] : need;
+        if (need > ctx->lv[L].cap_s) {
+            size_t w = ((size_t)need + need / 4 + 63) / 64 * 64;
+            if (w > ctx->want_cap_s[L]) ctx->want_cap_s[L] = (uint32_t)w;
+            // its children were not all created: start the next level at least as large
+            if (L + 1 < RTU_MAX_LEVELS && ctx->want_cap_s[L + 1] < w && ctx->lv[L + 1].cap_s < w) ctx->want_cap_s[L + 1] = (uint32_t)w;
+            grew = true;
+        }
+    }
+    uint32_t dneed = 0;
+    for (int p = 0; p <= RTU_MAX_LEVELS; p++)
+        for (int s = 0; s < RTU_SHARDS; s++) dneed = h.n_defer[p][s] > dneed ? h.n_defer[p][s] : dneed;
+    if (dneed > ctx->defer_cap_s) {
+        ctx->want_defer_s = dneed + dneed / 4;
+        grew = true;
+    }
+    if (!grew) {  // should not happen: the flag is only set next to a counter that ran over
+        for (int L = 1; L < RTU_MAX_LEVELS; L++) ctx->want_cap_s[L] = ctx->lv[L].cap_s * 2;
+    }
     return RTU_OK;
 }
 
@@ -769,7 +810,8 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ctx->nsl = 0;
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
-    ctx->cap_scale = 1;
+    memset(ctx->want_cap_s, 0, sizeof ctx->want_cap_s);
+    ctx->want_defer_s = 0;
     ctx->n_meshes = s->n_meshes;
     ctx->mesh_info = mesh_info;
     ctx->any_recursive_material = false;
@@ -877,8 +919,9 @@ int rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, 
         bool overflow = false;
         if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
         if (!overflow) break;
-        if (attempt >= 4) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceed %ux the pixel count", ctx->cap_scale);
-        ctx->cap_scale *= 2;  // more frames than provisioned: grow the level arrays and render again
+        // more frames than provisioned: check_overflow has raised the wanted capacities; render again
+        // (every round settles at least one more recursion level)
+        if (attempt >= 2 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", attempt);
     }
     if (bytes) RTU_HIP(ctx, hipMemcpy(h_rgbz, ctx->fb, bytes, hipMemcpyDeviceToHost));
     if (stats) return rtu_get_stats(ctx, stats);
@@ -893,7 +936,6 @@ int rtu_frame_status(RtuContext* ctx) {
     int rc = check_overflow(ctx, &overflow);
     if (rc != RTU_OK) return rc;
     if (overflow) {
-        ctx->cap_scale *= 2;  // the next frame is rendered with twice the capacity
         return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity; render the frame again");
     }
     return RTU_OK;

@@ -321,6 +321,62 @@ def test_two_meshes_nested_transforms_glass_and_mirror(pkg, orc, ctx, tmp_path, 
     assert gst["secondary_rays"] > 5000 and gst["mesh_entries"] > 10000
 
 
+def test_frame_capacity_overflow_is_detected_and_repaired(pkg, orc, tmp_path):
+    """Level >= 1 frame arrays are provisioned for one frame per pixel; a view filled by a glass +
+    mirror sphere inside a room spawns up to three child frames per pixel. The synchronous entry
+    must notice the overflow, double the capacity and render again (transparently); the
+    asynchronous one must report RTU_ERR_CAPACITY from rtu_frame_status and succeed on the retry."""
+    xml = tmp_path / "glassroom.xml"
+    xml.write_text("""<xml><scene>
+      <object type="sphere" name="room" material="wall"><scale value="60"/></object>
+      <object type="sphere" name="ball" material="glassmirror"><scale value="9"/><translate x="0" y="0" z="0"/></object>
+      <material type="blinn" name="wall"><diffuse r="0.7" g="0.6" b="0.5"/><specular value="0.2"/><glossiness value="10"/></material>
+      <material type="blinn" name="glassmirror"><diffuse r="0.1" g="0.1" b="0.1"/><specular value="0.8"/><glossiness value="60"/>
+        <reflection value="0.4"/><refraction index="1.4" value="0.7"/></material>
+      <light type="ambient" name="a"><intensity value="0.3"/></light>
+      <light type="point" name="p"><intensity value="0.8"/><position x="10" y="-20" z="25"/></light>
+    </scene><camera><position x="0" y="-14" z="0"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="70"/>
+      <width value="128"/><height value="96"/></camera></xml>""")
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 128, 96
+    cpu, cst = orc.render(scene, W, H, threads=4)
+    ctx = pkg.Context(0)   # a fresh context: capacity scale 1
+    try:
+        ctx.upload(scene)
+        fr = pkg.frame_setup(scene.desc.camera, W, H)
+        nbytes = W * H * 16
+        d = pkg.hip.rtu_device_alloc(ctx._h, nbytes)
+        ctx.render_device(fr, d, None)
+        with pytest.raises(pkg.RtuError) as e:
+            ctx.frame_status()
+        assert e.value.code == pkg.RTU_ERR_CAPACITY
+        for _ in range(8):  # every report grows the capacity of at least one more recursion level
+            ctx.render_device(fr, d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as err:
+                assert err.code == pkg.RTU_ERR_CAPACITY
+        else:
+            raise AssertionError("capacity never sufficed")
+        out = np.empty((H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, nbytes) == 0
+        pkg.hip.rtu_device_free(ctx._h, d)
+        check_against(out, cpu, orc)
+        frames, _ = ctx.frame_counts()
+        assert frames[1] > W * H, frames  # more child frames than pixels: the case the test is about
+    finally:
+        ctx.close()
+    ctx2 = pkg.Context(0)  # synchronous entry on a fresh context: transparent retry
+    try:
+        ctx2.upload(scene)
+        img, gst = ctx2.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+        check_against(img, cpu, orc)
+        assert gst == cst
+    finally:
+        ctx2.close()
+
+
 @pytest.mark.parametrize("tag,coop", [("teapot2_240x135", True), ("teapot2_240x135", False), ("p11_240x135", False)])
 def test_walk_stack_overflow_falls_back_to_the_reference_tree(pkg, ctx, golden, tag, coop):
     """A walk of the 4-wide / 8-wide tree that would need more stack than it has finishes on the

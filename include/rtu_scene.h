@@ -127,6 +127,29 @@ typedef struct RtuCamera {
     int32_t img_width, img_height;
 } RtuCamera;
 
+/* Texture (scene.h:308-365): an image file sampled bilinearly with tiling (TextureFile,
+ * texture.cpp:95-121) or a two-colour checker (TextureChecker, :125-133). */
+enum { RTU_TEX_FILE = 0, RTU_TEX_CHECKER = 1 };
+typedef struct RtuTexture {
+    int32_t  type;                /* RTU_TEX_* */
+    int32_t  width, height;       /* FILE: 0 x 0 when the file failed to load => samples black (texture.cpp:97) */
+    int32_t  reserved;
+    const uint8_t* rgb;           /* FILE: width*height Color24, rows as decoded (lodepng LCT_RGB / PPM P6) */
+    float    color1[3], color2[3];/* CHECKER */
+} RtuTexture;
+
+/* TextureMap = Transformation + Texture* (scene.h:375-397). present == 0: the TexturedColor has no
+ * map and samples its plain colour; present == 1 with texture == -1: TextureMap(NULL) => black. */
+typedef struct RtuTexMap {
+    int32_t present;
+    int32_t texture;              /* index into textures[] or -1 */
+    float   tm[9], itm[9], pos[3];/* TransformTo(p) = itm * (p - pos), scene.h:241 */
+    int32_t reserved;
+} RtuTexMap;                      /* 96 bytes */
+
+/* The four TexturedColors of a MtlBlinn, in this order in RtuSceneDesc.material_maps[4*m + k]. */
+enum { RTU_MAP_DIFFUSE = 0, RTU_MAP_SPECULAR = 1, RTU_MAP_REFLECTION = 2, RTU_MAP_REFRACTION = 3 };
+
 /* TexturedColor reduced to what the in-scope configs need: a constant colour,
  * or "a texture map whose file failed to load" which samples black
  * (scene.h:382,421). */
@@ -146,6 +169,12 @@ typedef struct RtuSceneDesc {
     RtuCamera   camera;
     RtuEnvColor background;
     RtuEnvColor environment;
+    /* textures ("next" row f2). n_textures == 0 and material_maps == NULL: an untextured scene. */
+    uint32_t n_textures, reserved0;
+    const RtuTexture* textures;
+    const RtuTexMap*  material_maps;   /* NULL or n_materials * 4 */
+    RtuTexMap background_map;          /* used when background.has_map && !map_is_null */
+    RtuTexMap environment_map;
 } RtuSceneDesc;
 
 #ifdef __cplusplus

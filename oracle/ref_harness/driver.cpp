@@ -104,6 +104,9 @@ struct Flat {
     };
     std::vector<MeshStore> meshStore;
     std::vector<RtuMesh> meshes;
+    std::vector<std::vector<uint8_t>> texData;
+    std::vector<RtuTexture> textures;
+    std::vector<RtuTexMap> maps;
 };
 
 static int MaterialIndex(const Material* m) {
@@ -190,8 +193,44 @@ static RtuEnvColor FlattenEnv(const TexturedColor& t) {
     e.color[0] = t.GetColor().r; e.color[1] = t.GetColor().g; e.color[2] = t.GetColor().b;
     e.has_map = t.GetTexture() ? 1 : 0;
     e.map_is_null = (t.GetTexture() && t.GetTexture()->texture == NULL) ? 1 : 0;
-    if (e.has_map && !e.map_is_null) fprintf(stderr, "WARNING: textured background/environment is outside the flattened format\n");
     return e;
+}
+
+// textureList (xmlload.cpp:29) -> RtuTexture[], in list order
+static void FlattenTextures(Flat& F) {
+    F.texData.resize(textureList.list.size());
+    for (size_t i = 0; i < textureList.list.size(); i++) {
+        const Texture* t = textureList.list[i]->GetObj();
+        RtuTexture o;
+        memset(&o, 0, sizeof o);
+        if (const TextureChecker* c = dynamic_cast<const TextureChecker*>(t)) {
+            o.type = RTU_TEX_CHECKER;
+            o.color1[0] = c->color1.r; o.color1[1] = c->color1.g; o.color1[2] = c->color1.b;
+            o.color2[0] = c->color2.r; o.color2[1] = c->color2.g; o.color2[2] = c->color2.b;
+        } else if (const TextureFile* f = dynamic_cast<const TextureFile*>(t)) {
+            o.type = RTU_TEX_FILE;
+            o.width = f->width; o.height = f->height;
+            F.texData[i].resize((size_t)f->width * f->height * 3);
+            for (size_t k = 0; k < f->data.size(); k++) {
+                F.texData[i][3 * k] = f->data[k].r; F.texData[i][3 * k + 1] = f->data[k].g; F.texData[i][3 * k + 2] = f->data[k].b;
+            }
+        } else { fprintf(stderr, "unknown texture class\n"); exit(2); }
+        F.textures.push_back(o);
+    }
+    for (size_t i = 0; i < F.textures.size(); i++) F.textures[i].rgb = F.texData[i].empty() ? NULL : F.texData[i].data();
+}
+static RtuTexMap FlattenMap(const TexturedColor& t) {
+    RtuTexMap m;
+    memset(&m, 0, sizeof m);
+    m.texture = -1;
+    const TextureMap* tm = t.GetTexture();
+    if (!tm) return m;
+    m.present = 1;
+    for (size_t i = 0; i < textureList.list.size(); i++)
+        if (textureList.list[i]->GetObj() == tm->texture) m.texture = (int32_t)i;
+    for (int k = 0; k < 9; k++) { m.tm[k] = tm->GetTransform().data[k]; m.itm[k] = tm->GetInverseTransform().data[k]; }
+    m.pos[0] = tm->GetPosition().x; m.pos[1] = tm->GetPosition().y; m.pos[2] = tm->GetPosition().z;
+    return m;
 }
 
 static void Flatten(Flat& F, RtuSceneDesc& d) {
@@ -211,10 +250,20 @@ static void Flatten(Flat& F, RtuSceneDesc& d) {
         m.ior = b->ior;
         m.reflection_glossiness = b->reflectionGlossiness;
         m.refraction_glossiness = b->refractionGlossiness;
-        if (b->diffuse.GetTexture() || b->specular.GetTexture() || b->reflection.GetTexture() || b->refraction.GetTexture())
-            fprintf(stderr, "WARNING: textured material is outside the flattened format\n");
+        // like the host loader: a map whose texture failed to load multiplies the colour by black (scene.h:382,421)
+        const TexturedColor* tcs[5] = {&b->diffuse, &b->specular, &b->reflection, &b->refraction, &b->emission};
+        float* dst[5] = {m.diffuse, m.specular, m.reflection, m.refraction, m.emission};
+        for (int k = 0; k < 5; k++)
+            if (tcs[k]->GetTexture() && !tcs[k]->GetTexture()->texture)
+                for (int j = 0; j < 3; j++) dst[k][j] = dst[k][j] * 0.0f;
         F.mats.push_back(m);
+        for (int k = 0; k < 4; k++) {
+            RtuTexMap tm = FlattenMap(*tcs[k]);
+            if (tm.present && tm.texture < 0) { memset(&tm, 0, sizeof tm); tm.texture = -1; }
+            F.maps.push_back(tm);
+        }
     }
+    FlattenTextures(F);
     for (size_t i = 0; i < lights.size(); i++) {
         RtuLight l;
         memset(&l, 0, sizeof l);
@@ -264,6 +313,15 @@ static void Flatten(Flat& F, RtuSceneDesc& d) {
     d.camera.img_width = camera.imgWidth; d.camera.img_height = camera.imgHeight;
     d.background = FlattenEnv(background);
     d.environment = FlattenEnv(environment);
+    bool any = false;
+    for (size_t i = 0; i < F.maps.size(); i++) any = any || F.maps[i].present;
+    d.n_textures = (uint32_t)F.textures.size();
+    d.textures = F.textures.empty() ? NULL : F.textures.data();
+    d.material_maps = any ? F.maps.data() : NULL;
+    d.background_map = FlattenMap(background);
+    d.environment_map = FlattenMap(environment);
+    if (d.background_map.texture < 0) { memset(&d.background_map, 0, sizeof(RtuTexMap)); d.background_map.texture = -1; }
+    if (d.environment_map.texture < 0) { memset(&d.environment_map, 0, sizeof(RtuTexMap)); d.environment_map.texture = -1; }
 }
 
 // ---- recipe W --------------------------------------------------------------

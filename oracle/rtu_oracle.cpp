@@ -419,12 +419,78 @@ inline V3 light_direction(const RtuLight& l, V3 p) {
     return mk(0, 0, 0);
 }
 
-// TexturedColor::Sample / SampleEnvironment (scene.h:421-431) for untextured
-// colours and for TextureMap(NULL) (scene.h:382: samples black).
-inline C3 env_sample(const RtuEnvColor& e) {
+// ---------------------------------------------------------------------------
+// Textures ("next" row f2): Texture::TileClamp (scene.h:354-365), TextureFile::Sample
+// (texture.cpp:95-121), TextureChecker::Sample (:125-133), TextureMap::Sample (scene.h:382),
+// TexturedColor::Sample / SampleEnvironment (scene.h:421-431). Point sampling only: the
+// reference's Shade() calls Sample(hInfo.uvw) without derivatives (mtlFunctions.cpp:132-289).
+inline V3 tile_clamp(V3 uvw) {
+    V3 u;
+    u.x = uvw.x - (int)uvw.x;
+    u.y = uvw.y - (int)uvw.y;
+    u.z = uvw.z - (int)uvw.z;
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+inline C3 c24(const uint8_t* p) { return mkc(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f); }  // Color24::ToColor, cyColor.h:214
+inline C3 texture_sample(const RtuTexture& t, V3 uvw) {
+    V3 u = tile_clamp(uvw);
+    if (t.type == RTU_TEX_CHECKER) {
+        if (u.x <= 0.5f) return u.y <= 0.5f ? ldc(t.color1) : ldc(t.color2);
+        return u.y <= 0.5f ? ldc(t.color2) : ldc(t.color1);
+    }
+    const int width = t.width, height = t.height;
+    if (width + height == 0) return mkc(0, 0, 0);
+    float x = width * u.x;
+    float y = height * u.y;
+    int ix = (int)x;
+    int iy = (int)y;
+    float fx = x - ix;
+    float fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1;
+    if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1;
+    if (iyp >= height) iyp -= height;
+    const uint8_t* d = t.rgb;
+    return ((c24(d + 3 * ((size_t)iy * width + ix)) * ((1 - fx) * (1 - fy)) + c24(d + 3 * ((size_t)iy * width + ixp)) * (fx * (1 - fy))) +
+            c24(d + 3 * ((size_t)iyp * width + ix)) * ((1 - fx) * fy)) +
+           c24(d + 3 * ((size_t)iyp * width + ixp)) * (fx * fy);
+}
+inline C3 map_sample(const RtuSceneDesc& s, const RtuTexMap& m, V3 uvw) {  // TextureMap::Sample
+    if (m.texture < 0) return mkc(0, 0, 0);
+    return texture_sample(s.textures[m.texture], mat_mul(m.itm, uvw - ld3(m.pos)));  // TransformTo, scene.h:235
+}
+// TexturedColor::Sample of material colour k (RTU_MAP_*)
+inline C3 mtl_color(const RtuSceneDesc& s, int mtl_id, int k, const float* color, V3 uvw) {
+    C3 c = ldc(color);
+    if (!s.material_maps) return c;
+    const RtuTexMap& m = s.material_maps[4 * mtl_id + k];
+    return m.present ? c * map_sample(s, m, uvw) : c;
+}
+inline C3 env_color_sample(const RtuSceneDesc& s, const RtuEnvColor& e, const RtuTexMap& m, V3 uvw) {
     C3 c = ldc(e.color);
-    if (e.has_map) return c * mkc(0, 0, 0);
-    return c;
+    if (!e.has_map) return c;
+    if (e.map_is_null || !m.present) return c * mkc(0, 0, 0);  // TextureMap(NULL) samples black
+    return c * map_sample(s, m, uvw);
+}
+// background.Sample(Point3(x/W, y/H, 0)), RenderFunctions.cpp:145
+inline C3 background_sample(const RtuSceneDesc& s, int x, int y) {
+    return env_color_sample(s, s.background, s.background_map, mk((float)x / s.camera.img_width, (float)y / s.camera.img_height, 0));
+}
+// environment.SampleEnvironment(dir), scene.h:425-431
+inline C3 env_sample(const RtuSceneDesc& s, V3 dir) {
+    if (!s.environment.has_map) return ldc(s.environment.color);
+    float z = asinf(-dir.z) / float(M_PI) + 0.5f;
+    float x = dir.x / (float)(fabs(dir.x) + fabs(dir.y));
+    float y = dir.y / (float)(fabs(dir.x) + fabs(dir.y));
+    V3 uvw = mk(0.5f, 0.5f, 0.0f) + (mk(0.5f, 0.5f, 0) * x + mk(-0.5f, 0.5f, 0) * y) * z;
+    return env_color_sample(s, s.environment, s.environment_map, uvw);
 }
 
 C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount);
@@ -451,7 +517,7 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
     const RtuMaterial& m = cx.s->materials[mtl_id];
     const RtuSceneDesc& s = *cx.s;
     C3 result = mkc(0, 0, 0);
-    C3 diffuse = ldc(m.diffuse), specular = ldc(m.specular);
+    C3 diffuse = mtl_color(s, mtl_id, RTU_MAP_DIFFUSE, m.diffuse, hInfo.uvw), specular = mtl_color(s, mtl_id, RTU_MAP_SPECULAR, m.specular, hInfo.uvw);
     if (hInfo.front) {  // :125
         for (uint32_t i = 0; i < s.n_lights; i++) {
             const RtuLight& l = s.lights[i];
@@ -470,7 +536,7 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
         }
     }
     if (bounceCount > 0) {
-        C3 refraction = ldc(m.refraction);
+        C3 refraction = mtl_color(s, mtl_id, RTU_MAP_REFRACTION, m.refraction, hInfo.uvw);
         if (not_black(refraction)) {  // :160
             V3 sampledNormal = sampled_normal(hInfo);
             float cosTheta1 = dot(sampledNormal, -ray.dir);
@@ -514,7 +580,7 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
                     C3 frenselResult;
                     cx.st.secondary_rays++;
                     if (trace(cx, reflected, 0, rh)) frenselResult = refraction * shade_node(cx, rh, reflected, bounceCount - 1);  // :247
-                    else frenselResult = env_sample(s.environment);                                                                // :250
+                    else frenselResult = env_sample(s, reflected.dir);                                                             // :250
                     C3 refractionResult = shade_node(cx, fh, refracted, bounceCount - 1);  // :254
                     C3 absorptionV = mkc(1, 1, 1);
                     if (!fh.front)
@@ -522,18 +588,18 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
                     result += ((absorptionV * refraction) * refractionResult) * (float)(1.0 - (double)ShlicksApprox) +
                               frenselResult * ShlicksApprox;  // :264
                 } else {
-                    result += env_sample(s.environment);  // :267
+                    result += env_sample(s, refracted.dir);  // :267
                 }
             }
         }
-        C3 reflection = ldc(m.reflection);
+        C3 reflection = mtl_color(s, mtl_id, RTU_MAP_REFLECTION, m.reflection, hInfo.uvw);
         if (not_black(reflection)) {  // :273
             V3 sampledNormal = sampled_normal(hInfo);
             Ray reflected; reflected.p = hInfo.p; reflected.dir = reflect_dir(ray.dir, sampledNormal);
             Hit rh = new_hit();
             cx.st.secondary_rays++;
             if (trace(cx, reflected, 0, rh)) result += reflection * shade_node(cx, rh, reflected, bounceCount - 1);  // :286
-            else result += env_sample(s.environment) * reflection;                                                    // :289
+            else result += env_sample(s, reflected.dir) * ldc(m.reflection);  // :289: reflection.GetColor(), not the sampled colour
         }
     }
     return result;
@@ -572,7 +638,6 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
     Ctx cx;
     cx.s = s;
     memset(&cx.st, 0, sizeof cx.st);
-    C3 bg = env_sample(s->background);  // background.Sample(...), RenderFunctions.cpp:145 (untextured)
     for (;;) {
         int y0 = next_row->fetch_add(chunk);
         if (y0 >= y_end) break;
@@ -590,7 +655,7 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
                     cx.st.primary_hits++;
                     c = shade_node(cx, h, ray, RTU_MAX_BOUNCE);  // :134-135
                 } else {
-                    c = bg;
+                    c = background_sample(*s, x, y);  // RenderFunctions.cpp:145
                 }
                 float* o = rgbz + 4 * ((size_t)(y - y_begin) * W + x);
                 o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = h.z;
@@ -604,8 +669,8 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
 int check_scene(const RtuSceneDesc* s) {
     if (!s || !s->nodes || s->n_nodes == 0) return RTU_ORACLE_ERR_ARG;
     if (s->camera.dof != 0) return RTU_ORACLE_ERR_STOCHASTIC;
-    if ((s->background.has_map && !s->background.map_is_null) || (s->environment.has_map && !s->environment.map_is_null))
-        return RTU_ORACLE_ERR_UNSUPPORTED;
+    for (uint32_t i = 0; i < s->n_textures; i++)
+        if (s->textures[i].type == RTU_TEX_FILE && s->textures[i].width * s->textures[i].height > 0 && !s->textures[i].rgb) return RTU_ORACLE_ERR_ARG;
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type == RTU_LIGHT_POINT && s->lights[i].size > 0) return RTU_ORACLE_ERR_STOCHASTIC;
     for (uint32_t i = 0; i < s->n_materials; i++)

@@ -51,11 +51,18 @@ class RtuEnvColor(ctypes.Structure):
                 ("reserved", ctypes.c_int32 * 3)]
 
 
+class RtuTexMap(ctypes.Structure):
+    _fields_ = [("present", ctypes.c_int32), ("texture", ctypes.c_int32), ("tm", ctypes.c_float * 9), ("itm", ctypes.c_float * 9),
+                ("pos", ctypes.c_float * 3), ("reserved", ctypes.c_int32)]
+
+
 class RtuSceneDesc(ctypes.Structure):
     _fields_ = [("n_nodes", ctypes.c_uint32), ("n_materials", ctypes.c_uint32), ("n_lights", ctypes.c_uint32),
                 ("n_meshes", ctypes.c_uint32), ("nodes", ctypes.c_void_p), ("materials", ctypes.c_void_p),
                 ("lights", ctypes.c_void_p), ("meshes", ctypes.c_void_p), ("camera", RtuCamera),
-                ("background", RtuEnvColor), ("environment", RtuEnvColor)]
+                ("background", RtuEnvColor), ("environment", RtuEnvColor),
+                ("n_textures", ctypes.c_uint32), ("reserved0", ctypes.c_uint32), ("textures", ctypes.c_void_p),
+                ("material_maps", ctypes.c_void_p), ("background_map", RtuTexMap), ("environment_map", RtuTexMap)]
 
 
 class RtuFrameDesc(ctypes.Structure):

@@ -400,8 +400,9 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
     if (s->n_lights && !s->lights) return fail(ctx, RTU_ERR_ARG, "lights is NULL");
     if (s->n_meshes && !s->meshes) return fail(ctx, RTU_ERR_ARG, "meshes is NULL");
     if (s->camera.dof != 0) return fail(ctx, RTU_ERR_STOCHASTIC, "depth of field is stochastic");
-    if ((s->background.has_map && !s->background.map_is_null) || (s->environment.has_map && !s->environment.map_is_null))
-        return fail(ctx, RTU_ERR_UNSUPPORTED, "textured background/environment");
+    if (s->n_textures > 0 || s->material_maps || (s->background.has_map && !s->background.map_is_null) ||
+        (s->environment.has_map && !s->environment.map_is_null))
+        return fail(ctx, RTU_ERR_UNSUPPORTED, "textures (SURVEY row f2: loader and oracle support them, the device path not yet)");
     for (uint32_t i = 0; i < s->n_lights; i++) {
         const RtuLight& l = s->lights[i];
         if (l.type < RTU_LIGHT_AMBIENT || l.type > RTU_LIGHT_POINT) return fail(ctx, RTU_ERR_ARG, "light %u: bad type", i);

@@ -21,8 +21,17 @@ struct MeshData {
     float    bound_max[3] = {0, 0, 0};
 };
 
+struct TextureData {
+    RtuTexture hdr{};               // rgb pointer is fixed up by Scene::rebuild_desc
+    std::vector<uint8_t> rgb;
+};
+
 // An owned flattened scene; `desc` always points into the vectors below.
 struct Scene {
+    std::vector<TextureData> textures;
+    std::vector<RtuTexture>  texture_descs;
+    std::vector<RtuTexMap>   material_maps;   // empty or 4 per material
+    RtuTexMap background_map{}, environment_map{};
     std::vector<RtuNode>     nodes;
     std::vector<RtuMaterial> materials;
     std::vector<RtuLight>    lights;

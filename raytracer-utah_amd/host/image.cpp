@@ -153,3 +153,135 @@ int rtu_image_save_zpng(const RtuImage* img, const char* path) {
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------
+// TextureFile::Load (texture.cpp:56-90): ".png" through a PNG decoder to 8-bit RGB (the reference
+// calls lodepng::decode(..., LCT_RGB)), ".ppm" as binary P6. Own decoder (zlib inflate + the five
+// PNG filters): 8-bit grey / RGB / palette / grey+alpha / RGBA, non-interlaced — what lodepng
+// converts losslessly to LCT_RGB 8; anything else fails to load, which the scene treats like a
+// missing file (TextureMap(NULL), samples black).
+#include "scene_graph.h"
+
+#include <cctype>
+
+namespace rtu {
+namespace {
+
+bool read_file(const char* path, std::vector<unsigned char>& out) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long n = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (n < 0) { fclose(fp); return false; }
+    out.resize((size_t)n);
+    bool ok = n == 0 || fread(out.data(), 1, (size_t)n, fp) == (size_t)n;
+    fclose(fp);
+    return ok;
+}
+uint32_t be32(const unsigned char* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+bool decode_png(const std::vector<unsigned char>& d, Texture& out) {
+    static const unsigned char sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) return false;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    size_t off = 8;
+    while (off + 12 <= d.size()) {
+        uint32_t len = be32(&d[off]);
+        const unsigned char* type = &d[off + 4];
+        if (off + 12 + (size_t)len > d.size()) return false;
+        const unsigned char* data = &d[off + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        off += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || depth != 8 || interlace != 0 || w > 32768 || h > 32768) return false;
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<unsigned char> img(stride * h);
+    for (uint32_t y = 0; y < h; y++) {
+        const unsigned char* in = &raw[(stride + 1) * y];
+        unsigned char* cur = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        const int f = in[0];
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)ch ? cur[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int v = in[1 + x];
+            if (f == 1) v += a;
+            else if (f == 2) v += b;
+            else if (f == 3) v += (a + b) / 2;
+            else if (f == 4) {
+                int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (f != 0) return false;
+            cur[x] = (unsigned char)v;
+        }
+    }
+    out.width = (int)w; out.height = (int)h;
+    out.rgb.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        unsigned char* o = &out.rgb[3 * i];
+        const unsigned char* p = &img[i * ch];
+        if (ctype == 2 || ctype == 6) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+        else if (ctype == 0 || ctype == 4) { o[0] = o[1] = o[2] = p[0]; }
+        else {  // palette
+            if ((size_t)p[0] * 3 + 2 >= plte.size()) return false;
+            o[0] = plte[p[0] * 3]; o[1] = plte[p[0] * 3 + 1]; o[2] = plte[p[0] * 3 + 2];
+        }
+    }
+    return true;
+}
+
+bool decode_ppm(const std::vector<unsigned char>& d, Texture& out) {  // LoadPPM, texture.cpp:17-52: binary "P6"
+    size_t off = 0;
+    auto token = [&](std::string& t) {
+        t.clear();
+        for (;;) {
+            while (off < d.size() && isspace(d[off])) off++;
+            if (off < d.size() && d[off] == '#') { while (off < d.size() && d[off] != '\n') off++; continue; }
+            break;
+        }
+        while (off < d.size() && !isspace(d[off])) t.push_back((char)d[off++]);
+        return !t.empty();
+    };
+    std::string t;
+    if (!token(t) || t != "P6") return false;
+    if (!token(t)) return false;
+    int w = atoi(t.c_str());
+    if (!token(t)) return false;
+    int h = atoi(t.c_str());
+    if (!token(t)) return false;  // "255"
+    off++;                        // the single whitespace after the header
+    if (w <= 0 || h <= 0 || off + (size_t)w * h * 3 > d.size()) return false;
+    out.width = w; out.height = h;
+    out.rgb.assign(d.begin() + (long)off, d.begin() + (long)(off + (size_t)w * h * 3));
+    return true;
+}
+
+}  // namespace
+
+bool LoadTextureFile(const char* filename, Texture& out) {
+    const size_t len = strlen(filename);
+    if (len < 3) return false;
+    char ext[4] = {(char)tolower(filename[len - 3]), (char)tolower(filename[len - 2]), (char)tolower(filename[len - 1]), 0};
+    std::vector<unsigned char> d;
+    if (!strcmp(ext, "png")) return read_file(filename, d) && decode_png(d, out);
+    if (!strcmp(ext, "ppm")) return read_file(filename, d) && decode_ppm(d, out);
+    return false;
+}
+
+}  // namespace rtu

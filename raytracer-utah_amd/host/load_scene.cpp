@@ -226,19 +226,37 @@ struct Loader {
         return p;
     }
 
-    // ReadTexture (xmlload.cpp:499-555) reduced to "is there a map, and is its texture NULL"
-    void ReadTexture(const XmlElement& e, TexturedColor& tc, const char* what) {
+    // ReadTexture (xmlload.cpp:499-555)
+    void ReadTexture(const XmlElement& e, TexturedColor& tc) {
         const char* texName = e.attr("texture");
         if (!texName) return;
-        tc.has_map = true;
-        bool real = false;
-        if (same(texName, "checkerboard")) real = true;
-        else {
-            std::string p = remap(texName);
-            if (FILE* fp = fopen(p.c_str(), "rb")) { real = true; fclose(fp); }  // loadable file => a real texture
+        const Texture* tex = nullptr;
+        if (same(texName, "checkerboard")) {
+            std::unique_ptr<Texture> c(new Texture);
+            c->type = RTU_TEX_CHECKER;
+            c->name = texName;
+            for (auto& ch : e.children) {
+                if (same(ch->name, "color1")) { Color col(0, 0, 0); ReadColor(*ch, col); c->color1 = col; }
+                else if (same(ch->name, "color2")) { Color col(0, 0, 0); ReadColor(*ch, col); c->color2 = col; }
+            }
+            tex = c.get();
+            sg.textureList.push_back(std::move(c));
+        } else {
+            for (auto& t : sg.textureList)
+                if (t->type == RTU_TEX_FILE && t->name == texName) tex = t.get();
+            if (!tex) {
+                std::unique_ptr<Texture> f(new Texture);
+                f->type = RTU_TEX_FILE;
+                f->name = texName;
+                if (LoadTextureFile(remap(texName).c_str(), *f)) {  // a file that fails to load leaves TextureMap(NULL): black
+                    tex = f.get();
+                    sg.textureList.push_back(std::move(f));
+                }
+            }
         }
-        tc.map_is_null = !real;
-        if (real && sg.error.empty()) sg.error = std::string("textured ") + what + " (\"" + texName + "\") is outside the device path (SURVEY row f2)";
+        tc.map.reset(new TextureMap);
+        tc.map->texture = tex;
+        LoadTransform(*tc.map, e);
     }
 
     // LoadTransform (xmlload.cpp:264-290): in XML child order
@@ -305,17 +323,17 @@ struct Loader {
         for (auto& c : e.children) {
             Color col(1, 1, 1);
             float f = 1;
-            if (same(c->name, "diffuse")) { ReadColor(*c, col); m->diffuse.SetColor(col); ReadTexture(*c, m->diffuse, "material"); }
-            else if (same(c->name, "specular")) { ReadColor(*c, col); m->specular.SetColor(col); ReadTexture(*c, m->specular, "material"); }
+            if (same(c->name, "diffuse")) { ReadColor(*c, col); m->diffuse.SetColor(col); ReadTexture(*c, m->diffuse); }
+            else if (same(c->name, "specular")) { ReadColor(*c, col); m->specular.SetColor(col); ReadTexture(*c, m->specular); }
             else if (same(c->name, "glossiness")) { ReadFloat(*c, f); m->glossiness = f; }
-            else if (same(c->name, "emission")) { ReadColor(*c, col); m->emission.SetColor(col); ReadTexture(*c, m->emission, "material"); }
+            else if (same(c->name, "emission")) { ReadColor(*c, col); m->emission.SetColor(col); ReadTexture(*c, m->emission); }
             else if (same(c->name, "reflection")) {
-                ReadColor(*c, col); m->reflection.SetColor(col); ReadTexture(*c, m->reflection, "material");
+                ReadColor(*c, col); m->reflection.SetColor(col); ReadTexture(*c, m->reflection);
                 f = 0; ReadFloat(*c, f, "glossiness"); m->reflectionGlossiness = f;
             } else if (same(c->name, "refraction")) {
                 ReadColor(*c, col); m->refraction.SetColor(col);
                 ReadFloat(*c, f, "index"); m->ior = f;
-                ReadTexture(*c, m->refraction, "material");
+                ReadTexture(*c, m->refraction);
                 f = 0; ReadFloat(*c, f, "glossiness"); m->refractionGlossiness = f;
             } else if (same(c->name, "absorption")) { ReadColor(*c, col); m->absorption = col; }
         }
@@ -383,14 +401,14 @@ bool LoadScene(const char* filename, const std::string& remap_from, const std::s
     Loader L{sg, remap_from, remap_to, {}};
     for (auto& c : scene->children) {  // LoadScene(TiXmlElement*), xmlload.cpp:139-163
         if (same(c->name, "background")) {
-            Color col(1, 1, 1); ReadColor(*c, col); sg.background.SetColor(col); L.ReadTexture(*c, sg.background, "background");
+            Color col(1, 1, 1); ReadColor(*c, col); sg.background.SetColor(col); L.ReadTexture(*c, sg.background);
         } else if (same(c->name, "environment")) {
-            Color col(1, 1, 1); ReadColor(*c, col); sg.environment.SetColor(col); L.ReadTexture(*c, sg.environment, "environment");
+            Color col(1, 1, 1); ReadColor(*c, col); sg.environment.SetColor(col); L.ReadTexture(*c, sg.environment);
         } else if (same(c->name, "object")) L.LoadNode(&sg.rootNode, *c);
         else if (same(c->name, "material")) L.LoadMaterial(*c);
         else if (same(c->name, "light")) L.LoadLight(*c);
     }
-    // a map whose texture is NULL samples black and is fine for the device path
+
     for (auto& nm : L.nodeMtlList)  // xmlload.cpp:100-106: first material with that exact name
         for (auto& m : sg.materials)
             if (m->name == nm.second) { nm.first->mtl = m.get(); break; }
@@ -455,9 +473,26 @@ RtuEnvColor flatten_env(const TexturedColor& t) {
     RtuEnvColor e;
     memset(&e, 0, sizeof e);
     e.color[0] = t.color.r; e.color[1] = t.color.g; e.color[2] = t.color.b;
-    e.has_map = t.has_map ? 1 : 0;
-    e.map_is_null = t.map_is_null ? 1 : 0;
+    e.has_map = t.map ? 1 : 0;
+    e.map_is_null = (t.map && !t.map->texture) ? 1 : 0;
     return e;
+}
+
+// TextureMap -> RtuTexMap; textures are numbered in textureList order
+RtuTexMap flatten_map(const SceneGraph& sg, const TexturedColor& t) {
+    RtuTexMap m;
+    memset(&m, 0, sizeof m);
+    m.texture = -1;
+    if (!t.map) return m;
+    m.present = 1;
+    for (size_t i = 0; i < sg.textureList.size(); i++)
+        if (sg.textureList[i].get() == t.map->texture) m.texture = (int32_t)i;
+    const Matrix3& tm = t.map->GetTransform();
+    const Matrix3& itm = t.map->GetInverseTransform();
+    const Point3 pos = t.map->GetPosition();
+    for (int k = 0; k < 9; k++) { m.tm[k] = tm.data[k]; m.itm[k] = itm.data[k]; }
+    m.pos[0] = pos.x; m.pos[1] = pos.y; m.pos[2] = pos.z;
+    return m;
 }
 
 }  // namespace
@@ -468,6 +503,8 @@ Scene* Flatten(const SceneGraph& sg, std::string& err) {
         return nullptr;
     }
     std::unique_ptr<Scene> s(new Scene);
+    std::vector<RtuTexMap> maps;
+    bool any_map = false;
     for (auto& mp : sg.materials) {
         const MtlBlinn* b = dynamic_cast<const MtlBlinn*>(mp.get());
         RtuMaterial m;
@@ -484,13 +521,32 @@ Scene* Flatten(const SceneGraph& sg, std::string& err) {
         m.ior = b->ior;
         m.reflection_glossiness = b->reflectionGlossiness;
         m.refraction_glossiness = b->refractionGlossiness;
-        // a material map whose texture failed to load multiplies the colour by black (scene.h:382,421)
+        // a material map whose texture failed to load multiplies the colour by black (scene.h:382,421):
+        // folded into the colour, so that such a scene stays an untextured one
         const TexturedColor* tcs[5] = {&b->diffuse, &b->specular, &b->reflection, &b->refraction, &b->emission};
         float* dst[5] = {m.diffuse, m.specular, m.reflection, m.refraction, m.emission};
         for (int k = 0; k < 5; k++)
-            if (tcs[k]->has_map && tcs[k]->map_is_null)
+            if (tcs[k]->map && !tcs[k]->map->texture)
                 for (int j = 0; j < 3; j++) dst[k][j] = dst[k][j] * 0.0f;
         s->materials.push_back(m);
+        for (int k = 0; k < 4; k++) {
+            RtuTexMap tm = flatten_map(sg, *tcs[k]);
+            if (tm.present && tm.texture < 0) memset(&tm, 0, sizeof tm), tm.texture = -1;  // folded above
+            any_map = any_map || tm.present;
+            maps.push_back(tm);
+        }
+    }
+    if (any_map) s->material_maps = maps;
+    for (auto& t : sg.textureList) {
+        TextureData td;
+        memset(&td.hdr, 0, sizeof td.hdr);
+        td.hdr.type = t->type; td.hdr.width = t->width; td.hdr.height = t->height;
+        if (t->type == RTU_TEX_CHECKER) {
+            td.hdr.color1[0] = t->color1.r; td.hdr.color1[1] = t->color1.g; td.hdr.color1[2] = t->color1.b;
+            td.hdr.color2[0] = t->color2.r; td.hdr.color2[1] = t->color2.g; td.hdr.color2[2] = t->color2.b;
+        }
+        td.rgb = t->rgb;
+        s->textures.push_back(std::move(td));
     }
     for (auto& lp : sg.lights) {
         RtuLight l;
@@ -516,6 +572,14 @@ Scene* Flatten(const SceneGraph& sg, std::string& err) {
     o.img_width = c.imgWidth; o.img_height = c.imgHeight;
     s->background = flatten_env(sg.background);
     s->environment = flatten_env(sg.environment);
+    // a map whose texture is NULL is fully described by RtuEnvColor (has_map, map_is_null): no RtuTexMap
+    auto real_map = [&](const TexturedColor& t) {
+        RtuTexMap m = flatten_map(sg, t);
+        if (m.texture < 0) { memset(&m, 0, sizeof m); m.texture = -1; }
+        return m;
+    };
+    s->background_map = real_map(sg.background);
+    s->environment_map = real_map(sg.environment);
     s->rebuild_desc();
     return s.release();
 }

@@ -5,6 +5,7 @@
 // that has no scene files. Layout (little endian, every section 16-byte
 // aligned):
 //   BlobHeader | nodes | materials | lights | per mesh: MeshHeader v f vn fn vt ft bvh elements
+//   [ | per texture: TexHeader rgb | material maps | background map | environment map ]   (textured scenes only)
 #include "host_internal.h"
 
 #include <cstdio>
@@ -27,7 +28,15 @@ struct BlobHeader {
     uint32_t    n_nodes, n_materials, n_lights, n_meshes;
     RtuCamera   camera;
     RtuEnvColor background, environment;
-    uint32_t    pad[4];
+    uint32_t    n_textures;      // 0 in the blobs of untextured scenes (the field was padding): no texture section
+    uint32_t    has_maps;        // 1: material maps (4 per material) + background + environment maps follow the textures
+    uint32_t    pad[2];
+};
+
+struct TexHeader {
+    int32_t type, width, height, reserved;
+    float   color1[3], color2[3];
+    uint32_t pad[2];
 };
 
 struct MeshHeader {
@@ -42,6 +51,8 @@ static_assert(sizeof(RtuLight) == 32, "RtuLight layout");
 static_assert(sizeof(RtuBvhNode) == 32, "RtuBvhNode layout");
 static_assert(sizeof(BlobHeader) % 16 == 0, "BlobHeader alignment");
 static_assert(sizeof(MeshHeader) % 16 == 0, "MeshHeader alignment");
+static_assert(sizeof(TexHeader) % 16 == 0, "TexHeader alignment");
+static_assert(sizeof(RtuTexMap) == 96, "RtuTexMap layout");
 
 struct Writer {
     std::vector<unsigned char> buf;
@@ -74,6 +85,15 @@ Scene* Scene::from_desc(const RtuSceneDesc& d) {
     s->camera = d.camera;
     s->background = d.background;
     s->environment = d.environment;
+    s->textures.resize(d.n_textures);
+    for (uint32_t i = 0; i < d.n_textures; i++) {
+        s->textures[i].hdr = d.textures[i];
+        const size_t n = d.textures[i].type == RTU_TEX_FILE ? size_t(d.textures[i].width) * d.textures[i].height * 3 : 0;
+        if (n && d.textures[i].rgb) s->textures[i].rgb.assign(d.textures[i].rgb, d.textures[i].rgb + n);
+    }
+    if (d.material_maps) s->material_maps.assign(d.material_maps, d.material_maps + size_t(d.n_materials) * 4);
+    s->background_map = d.background_map;
+    s->environment_map = d.environment_map;
     s->meshes.resize(d.n_meshes);
     for (uint32_t i = 0; i < d.n_meshes; i++) {
         const RtuMesh& m = d.meshes[i];
@@ -130,6 +150,16 @@ void Scene::rebuild_desc() {
     desc.camera = camera;
     desc.background = background;
     desc.environment = environment;
+    texture_descs.resize(textures.size());
+    for (size_t i = 0; i < textures.size(); i++) {
+        texture_descs[i] = textures[i].hdr;
+        texture_descs[i].rgb = textures[i].rgb.empty() ? nullptr : textures[i].rgb.data();
+    }
+    desc.n_textures = uint32_t(textures.size());
+    desc.textures = texture_descs.empty() ? nullptr : texture_descs.data();
+    desc.material_maps = material_maps.size() == materials.size() * 4 && !material_maps.empty() ? material_maps.data() : nullptr;
+    desc.background_map = background_map;
+    desc.environment_map = environment_map;
 }
 
 static void* to_blob(const RtuSceneDesc& d, size_t* size_out) {
@@ -144,6 +174,9 @@ static void* to_blob(const RtuSceneDesc& d, size_t* size_out) {
     h.camera = d.camera;
     h.background = d.background;
     h.environment = d.environment;
+    const bool textured = d.n_textures > 0;  // maps without a texture are folded away by the flatteners
+    h.n_textures = d.n_textures;
+    h.has_maps = textured ? 1u : 0u;
     w.put(&h, sizeof h);
     w.put(d.nodes, sizeof(RtuNode) * d.n_nodes);
     w.put(d.materials, sizeof(RtuMaterial) * d.n_materials);
@@ -165,6 +198,23 @@ static void* to_blob(const RtuSceneDesc& d, size_t* size_out) {
         w.put(m.ft, mh.nvt ? sizeof(uint32_t) * 3 * m.nf : 0);
         w.put(m.bvh, sizeof(RtuBvhNode) * m.n_bvh_nodes);
         w.put(m.elements, sizeof(uint32_t) * m.n_elements);
+    }
+    if (textured) {
+        for (uint32_t i = 0; i < d.n_textures; i++) {
+            const RtuTexture& t = d.textures[i];
+            TexHeader th;
+            memset(&th, 0, sizeof th);
+            th.type = t.type; th.width = t.width; th.height = t.height;
+            memcpy(th.color1, t.color1, sizeof th.color1);
+            memcpy(th.color2, t.color2, sizeof th.color2);
+            w.put(&th, sizeof th);
+            w.put(t.rgb, (t.type == RTU_TEX_FILE && t.rgb) ? size_t(t.width) * t.height * 3 : 0);
+        }
+        std::vector<RtuTexMap> none(size_t(d.n_materials) * 4);
+        memset(none.data(), 0, none.size() * sizeof(RtuTexMap));
+        w.put(d.material_maps ? d.material_maps : none.data(), sizeof(RtuTexMap) * d.n_materials * 4);
+        w.put(&d.background_map, sizeof(RtuTexMap));
+        w.put(&d.environment_map, sizeof(RtuTexMap));
     }
     void* out = malloc(w.buf.size());
     if (!out) return nullptr;
@@ -221,6 +271,31 @@ static Scene* from_blob(const void* blob, size_t size) {
              r.take(o.vt.data(), o.vt.size() * 4) && r.take(o.ft.data(), o.ft.size() * 4) &&
              r.take(o.bvh.data(), o.bvh.size() * sizeof(RtuBvhNode)) &&
              r.take(o.elements.data(), o.elements.size() * 4);
+    }
+    if (ok && h.has_maps) {
+        if (size_t(h.n_textures) * sizeof(TexHeader) > size) ok = false;
+        s->textures.resize(ok ? h.n_textures : 0);
+        for (uint32_t i = 0; ok && i < h.n_textures; i++) {
+            TexHeader th;
+            ok = r.take(&th, sizeof th);
+            if (!ok) break;
+            TextureData& t = s->textures[i];
+            t.hdr.type = th.type; t.hdr.width = th.width; t.hdr.height = th.height;
+            memcpy(t.hdr.color1, th.color1, sizeof th.color1);
+            memcpy(t.hdr.color2, th.color2, sizeof th.color2);
+            size_t n = 0;
+            if (th.type == RTU_TEX_FILE) {
+                if (th.width < 0 || th.height < 0 || size_t(th.width) * size_t(th.height) * 3 > size) { ok = false; break; }
+                n = size_t(th.width) * th.height * 3;
+            }
+            t.rgb.resize(n);
+            ok = r.take(t.rgb.data(), n);
+        }
+        s->material_maps.resize(size_t(h.n_materials) * 4);
+        ok = ok && r.take(s->material_maps.data(), sizeof(RtuTexMap) * s->material_maps.size()) &&
+             r.take(&s->background_map, sizeof(RtuTexMap)) && r.take(&s->environment_map, sizeof(RtuTexMap));
+        for (size_t i = 0; ok && i < s->material_maps.size(); i++)
+            if (s->material_maps[i].present && s->material_maps[i].texture >= (int32_t)h.n_textures) ok = false;
     }
     if (!ok) {
         set_error("scene blob: truncated");

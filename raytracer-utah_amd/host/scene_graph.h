@@ -93,11 +93,27 @@ void ComputeNormals(MeshData& m);                                               
 void ComputeBoundingBox(MeshData& m);                                                    // cyTriMesh.h:226-246
 void BuildBVH(MeshData& m, unsigned maxElementsPerNode);                                 // cyBVH.h:122-142,242-328
 
-// scene.h:405-433, reduced: colour + "has a texture map" + "the map's texture is NULL"
+// Texture (scene.h:308-365): TextureFile (texture.h:14-31) or TextureChecker (:34-46); the sampling
+// itself happens on the device / in the oracle, here they are data.
+struct Texture {
+    int type = RTU_TEX_CHECKER;
+    std::string name;                 // file textures are shared by name (textureList.Find, xmlload.cpp:538)
+    int width = 0, height = 0;
+    std::vector<uint8_t> rgb;         // width*height*3
+    Color color1 = Color(0, 0, 0), color2 = Color(1, 1, 1);  // TextureChecker(), texture.h:37
+};
+bool LoadTextureFile(const char* filename, Texture& out);  // TextureFile::Load (texture.cpp:56-90): .png / .ppm
+
+// TextureMap (scene.h:375-397): a texture (may be NULL) under its own transformation
+class TextureMap : public Transformation {
+public:
+    const Texture* texture = nullptr;
+};
+
+// TexturedColor (scene.h:405-433)
 struct TexturedColor {
     Color color;
-    bool  has_map = false;
-    bool  map_is_null = false;
+    std::unique_ptr<TextureMap> map;
     void SetColor(const Color& c) { color = c; }
 };
 
@@ -175,6 +191,7 @@ struct SceneGraph {
     std::vector<std::unique_ptr<Light>>    lights;
     std::vector<std::pair<std::string, std::unique_ptr<TriObj>>> objList;
     TexturedColor background, environment;
+    std::vector<std::unique_ptr<Texture>> textureList;  // xmlload.cpp:45
     std::string error;   // why the scene cannot be flattened (e.g. a textured material), empty if fine
 };
 

@@ -17,6 +17,7 @@ EXTRA_TAGS = ["p1test_200x150", "p2_200x150", "p3box_200x150", "p5_200x150", "p5
               "p13_200x150"]  # the reference's other deterministic scenes
 SMALL_TAGS = SMALL_TAGS + EXTRA_TAGS
 ALL_TAGS = SMALL_TAGS + FULL_TAGS
+TEX_TAGS = ["p7_200x150"]  # textured
 
 
 def pytest_configure(config):

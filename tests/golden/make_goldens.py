@@ -43,6 +43,8 @@ CONFIGS = [
     ("p5low_200x150", "Project5/scene-low.xml", 200, 150, True),
     ("p11simple_200x150", "Project11/scene_simple.xml", 200, 150, True),
     ("p13_200x150", "Project13/scene.xml", 200, 150, True),
+    # textures ("next" row f2): checkerboards, two 1024x1024 PNGs (mesh diffuse, background, environment)
+    ("p7_200x150", "Project7/scene.xml", 200, 150, True),
 ]
 
 

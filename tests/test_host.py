@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ALL_TAGS, REFERENCE, REPO, SMALL_TAGS, read_png
+from conftest import ALL_TAGS, REFERENCE, REPO, SMALL_TAGS, TEX_TAGS, read_png
 
 MAC_PREFIX = "/Users/Peter/GitRepos/RayTracer-Utah"
 SCENES = {
@@ -19,6 +19,7 @@ SCENES = {
     "p1test_200x150": "Project1Test.xml", "p2_200x150": "Project2.xml", "p3box_200x150": "Project3Box.xml",
     "p5_200x150": "Project5/scene.xml", "p5low_200x150": "Project5/scene-low.xml",
     "p11simple_200x150": "Project11/scene_simple.xml", "p13_200x150": "Project13/scene.xml",
+    "p7_200x150": "Project7/scene.xml",
 }
 
 
@@ -56,7 +57,7 @@ def test_no_gpu_means_error_code_not_crash(pkg):
     assert b"GPU" in pkg.hip.rtu_error_string(err.value)
 
 
-@pytest.mark.parametrize("tag", ALL_TAGS)
+@pytest.mark.parametrize("tag", ALL_TAGS + TEX_TAGS)
 def test_blob_round_trip(pkg, golden, tag):
     g = golden(tag)
     s = g.scene(pkg)
@@ -81,7 +82,7 @@ def test_blob_rejects_garbage(pkg, golden):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="scene files only exist in the authoring container")
-@pytest.mark.parametrize("tag", ALL_TAGS)
+@pytest.mark.parametrize("tag", ALL_TAGS + TEX_TAGS)
 def test_loader_matches_reference_scene_values(pkg, golden, tag):
     """Own XML + OBJ reader + BVH build vs the blob dumped from the reference's in-memory
     scene graph after ITS LoadScene(): every float of every node/material/light/camera,
@@ -172,7 +173,7 @@ def test_shard_arithmetic(pkg, golden):
             assert sorted(seen) == list(range(H)), (H, G)
 
 
-@pytest.mark.parametrize("tag", SMALL_TAGS)
+@pytest.mark.parametrize("tag", SMALL_TAGS + TEX_TAGS)
 def test_render_image_mirror_matches_reference(pkg, orc, golden, tag, tmp_path):
     """rtu_image_* (gamma, Color24, z-image, PNG) on the oracle's float output must give
     the reference's Result / ZBuffer pixels exactly; bands may arrive in any order."""

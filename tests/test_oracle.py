@@ -6,10 +6,10 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFERENCE, SMALL_TAGS, read_png, sha256
+from conftest import REFERENCE, SMALL_TAGS, TEX_TAGS, read_png, sha256
 
 
-@pytest.mark.parametrize("tag", SMALL_TAGS)
+@pytest.mark.parametrize("tag", SMALL_TAGS + TEX_TAGS)
 def test_oracle_bit_exact_vs_reference_golden(pkg, orc, golden, tag):
     g = golden(tag)
     scene = g.scene(pkg)
@@ -47,7 +47,7 @@ def test_oracle_full_size_hashes(pkg, orc, golden, tag):
         g.meta["primary_hits"], g.meta["secondary"], g.meta["shadow"])
 
 
-@pytest.mark.parametrize("tag", SMALL_TAGS)
+@pytest.mark.parametrize("tag", SMALL_TAGS + TEX_TAGS)
 def test_oracle_postprocess_matches_reference_pngs(pkg, orc, golden, tag):
     """gamma + Color24 + ComputeZBufferImage against the PNGs the reference wrote."""
     g = golden(tag)

@@ -112,17 +112,18 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
 }
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
-__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N) {
+template <bool TEX>
+__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw) {
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
     uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
     if (front && s.n_lights > 0) info |= RTU_FI_SH;                      // mtlFunctions.cpp:125
     if (bounce > 0) {                                                   // :158
-        if (not_black(ld3(m.refraction))) {                             // :160
+        if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
             info |= RTU_FI_MAIN;
             Refr r = refraction_terms(dir, p, N, front, m.ior);
             if (r.sinTheta2 > 1) info |= RTU_FI_TIR;                    // :205
         }
-        if (not_black(ld3(m.reflection))) info |= RTU_FI_C;             // :273
+        if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw))) info |= RTU_FI_C;  // :273
     }
     return info;
 }
@@ -202,7 +203,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
 }
 
 // ---- the primary ray of one pixel -------------------------------------------------------
-template <int STACK, bool STATS, bool DEFER, bool COOP = false>
+template <int STACK, bool STATS, bool DEFER, bool COOP, bool TEX>
 __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t pix, uint32_t shard,
                                               uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
                                               const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
@@ -220,10 +221,10 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEX>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
         if (!deferred && leader) {
             if (!hit) {
-                f3 bg = ld3(s.background);  // :145
+                f3 bg = background_sample<TEX>(s, x, y);  // :145
                 a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
             } else {
                 RTU_CNT(prim_hit);
@@ -240,7 +241,8 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         const LevelBuffers& lv = a.lv[0];
         if (fl < lv.cap_s) {
             const uint32_t idx = fl + shard * lv.cap_s;
-            info = make_info(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N);
+            info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw);
+            if (TEX) lv.fuv[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
             lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
@@ -253,7 +255,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
-template <int STACK, bool STATS>
+template <int STACK, bool STATS, bool TEX>
 __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
     const Stamp stamp(a, RTU_TL_PRIMARY);
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     const uint32_t shard = tile % RTU_SHARDS;
     Counters cnt = {};
     bool deferred;
-    primary_pixel<STACK, STATS, !STATS>(a, valid, x, y, pix, shard, stk, cnt, deferred);
+    primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, pix, shard, stk, cnt, deferred);
     if (!STATS) defer_push(a, 0, shard, deferred, pix);
     flush_counters<STATS>(a, cnt);
 }
@@ -288,7 +290,7 @@ __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nod
 }
 
 // stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
-template <int STACK>
+template <int STACK, bool TEX>
 __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2);
     __shared__ uint32_t s_stack[STACK * 64];
@@ -310,13 +312,13 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
         const int x = (int)(pix - ly * (uint32_t)a.frame.width);
         const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
         bool deferred;
-        primary_pixel<STACK, false, false, false>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
+        primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
     }
 }
 
 // stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
 // (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
-template <int STACK>
+template <int STACK, bool TEX>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2C);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
@@ -346,14 +348,14 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
         const int x = (int)(pix - ly * (uint32_t)a.frame.width);
         const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
         bool deferred;
-        primary_pixel<RTU_STACK8, false, false, true>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
+        primary_pixel<RTU_STACK8, false, false, true, TEX>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
 // ---- one ray of one frame ------------------------------------------------------------------
 // slot < nsl: shadow ray of non-ambient light `slot`; else secondary ray slot - nsl.
 // Returns true if the ray was deferred (DEFER only).
-template <int STACK, bool STATS, bool DEFER, bool COOP = false>
+template <int STACK, bool STATS, bool DEFER, bool COOP, bool TEX>
 __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt,
                                           bool leader = true, const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
@@ -397,7 +399,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     Hit h;
     fresh_hit(h, tmax);
     bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
+    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEX>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
     if (DEFER && deferred) return true;
     if (!leader) return false;
     if (is_shadow) {
@@ -409,12 +411,13 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
         slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
         slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
+        if (TEX) lv.fsuv[(size_t)f * 3 + sslot] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
     }
     return false;
 }
 
 // stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
-template <int STACK, bool STATS>
+template <int STACK, bool STATS, bool TEX>
 __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
@@ -460,14 +463,14 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
         const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
         const uint32_t f = shard * lv.cap_s + fl;
         bool deferred = false;
-        if (active) deferred = frame_ray<STACK, STATS, !STATS>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
+        if (active) deferred = frame_ray<STACK, STATS, !STATS, false, TEX>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
         if (!STATS) defer_push(a, ph, shard, deferred, (slot << 28) | f);
     }
     flush_counters<STATS>(a, cnt);
 }
 
 // stage 2, long lists: one lane per deferred ray
-template <int STACK>
+template <int STACK, bool TEX>
 __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
     __shared__ uint32_t s_stack[STACK * 64];
@@ -484,12 +487,12 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
         const uint32_t e = k * 64u + lane;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<STACK, false, false, false>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
+        frame_ray<STACK, false, false, false, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
     }
 }
 
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
-template <int STACK>
+template <int STACK, bool TEX>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
@@ -512,20 +515,25 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
         const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<RTU_STACK8, false, false, true>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
+        frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
 // ------------------------------------------------------------------------------------
 // MtlBlinn::Shade combination (mtlFunctions.cpp:205-291) once every child result is
 // known. st* >= 0 or RTU_CH_WHITE: that ray hit and ret* holds Shade() of the hit.
+template <bool TEX>
 __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMaterial& m, uint32_t info, f3 direct, f3 dir, f3 p,
-                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront) {
-    const f3 env = ld3(s.environment);
+                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront, f3 uvw) {
     const bool front = (info & RTU_FI_FRONT) != 0;
+    const int mtl = (int)(info & RTU_FI_MTL_MASK);
+    // environment.SampleEnvironment(direction of the ray that missed); a constant without an environment map
+    auto env_at = [&](int slot) {
+        return (TEX && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m.ior)) : ld3(s.environment);
+    };
     f3 result = direct;
     if (info & RTU_FI_MAIN) {
-        const f3 refraction = ld3(m.refraction), absorption = ld3(m.absorption);
+        const f3 refraction = mtl_color<TEX>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw), absorption = ld3(m.absorption);
         const bool mainHit = stMain >= 0 || stMain == RTU_CH_WHITE;
         if (info & RTU_FI_TIR) {
             if (mainHit) result = result + absorb(RTU_BIGFLOAT, absorption) * retMain;  // :210-221 (z of a fresh HitInfo)
@@ -536,22 +544,21 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
             if (!bfront) absorptionV = absorb(bz, absorption);                           // :258-262
             f3 term1 = ((absorptionV * refraction) * retMain) * (float)(1.0 - (double)S);
             const bool aHit = stA >= 0 || stA == RTU_CH_WHITE;
-            f3 frenselResult = aHit ? refraction * retA : env;                           // :247 / :250
+            f3 frenselResult = aHit ? refraction * retA : env_at(SLOT_A);  // :247 / :250
             result = result + (term1 + frenselResult * S);                               // :264
         } else {
-            result = result + env;                                                       // :267
+            result = result + env_at(SLOT_MAIN);  // :267
         }
     }
     if (info & RTU_FI_C) {
-        const f3 reflection = ld3(m.reflection);
         const bool cHit = stC >= 0 || stC == RTU_CH_WHITE;
-        if (cHit) result = result + reflection * retC;                                   // :286
-        else result = result + env * reflection;                                         // :289
+        if (cHit) result = result + mtl_color<TEX>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw) * retC;  // :286
+        else result = result + env_at(SLOT_C) * ld3(m.reflection);  // :289: GetColor()
     }
     return result;
 }
 
-template <bool STATS>
+template <bool STATS, bool TEX>
 __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
     const DevScene& s = a.scene;
@@ -574,11 +581,18 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
         const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
         const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
         const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
+        f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
+        if (TEX && active) {
+            const float4 t = lv.fuv[f];
+            uvw = mk3(t.x, t.y, t.z);
+        }
 
         // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
         f3 direct = mk3(0, 0, 0);
         if (active && (info & RTU_FI_SH)) {
-            const f3 diffuse = ld3(m.diffuse), specular = ld3(m.specular);
+            const int mtl = (int)(info & RTU_FI_MTL_MASK);
+            const f3 diffuse = mtl_color<TEX>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
+            const f3 specular = mtl_color<TEX>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
             uint32_t j = 0;  // index among the non-ambient lights
             for (uint32_t i = 0; i < s.n_lights; i++) {
                 const RTU_CONST RtuLight& l = as_const(s.lights)[i];
@@ -646,7 +660,13 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
                     // the child Shade(): ray direction, hit point and normal of the secondary ray
                     const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
                     const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
-                    cinfo = make_info(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN);
+                    f3 cuvw = mk3(0, 0, 0);
+                    if (TEX) {
+                        const float4 t = lv.fsuv[(size_t)f * 3 + k];
+                        cuvw = mk3(t.x, t.y, t.z);
+                        nx.fuv[idx] = t;
+                    }
+                    cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN, cuvw);
                     nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
                     nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
                     nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0.w);
@@ -668,7 +688,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
         if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
         if (!pending) {
             const f3 one = mk3(1, 1, 1);
-            const f3 r = finalize(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront);
+            const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw);
             if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
             else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
         } else {
@@ -678,6 +698,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
 }
 
 // Frames that waited for children: combine bottom-up.
+template <bool TEX>
 __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_COMBINE0 + L);
     const DevScene& s = a.scene;
@@ -719,7 +740,12 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
             bz = slotp[0].w;
             bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
         }
-        const f3 r = finalize(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront);
+        f3 uvw = mk3(0, 0, 0);
+        if (TEX) {
+            const float4 t = lv.fuv[f];
+            uvw = mk3(t.x, t.y, t.z);
+        }
+        const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw);
         if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
         else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
     }
@@ -802,7 +828,7 @@ __global__ void k_selftest_prims(unsigned long long n_rays, unsigned long long s
     if (bad) atomicAdd(mismatches, bad);
 }
 
-template <int STACK>
+template <int STACK, bool TEX>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
@@ -812,31 +838,31 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
     if (stats) {
-        hipLaunchKernelGGL((k_primary<STACK, true>), gridP, dim3(256), 0, stream, a, n_tiles);
+        hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
-        hipLaunchKernelGGL((k_primary<STACK, false>), gridP, dim3(256), 0, stream, a, n_tiles);
+        hipLaunchKernelGGL((k_primary<STACK, false, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
-            hipLaunchKernelGGL((k_primary2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
-            hipLaunchKernelGGL((k_primary2<STACK>), gridN, block, 0, stream, a);
+            hipLaunchKernelGGL((k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
+            hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
         }
     }
     for (int L = 0; L < levels; L++) {
         const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
-            hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
-            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
-            hipLaunchKernelGGL((k_consume<true>), gridF, block, 0, stream, a, L);
+            hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
+            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
+            hipLaunchKernelGGL((k_consume<true, TEX>), gridF, block, 0, stream, a, L);
         } else {
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
-            hipLaunchKernelGGL((k_trace<STACK, false>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
+            hipLaunchKernelGGL((k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
             if (a.n_meshes) {
-                hipLaunchKernelGGL((k_trace2c<STACK>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
-                hipLaunchKernelGGL((k_trace2<STACK>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
+                hipLaunchKernelGGL((k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
+                hipLaunchKernelGGL((k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
             }
-            hipLaunchKernelGGL((k_consume<false>), gridF, block, 0, stream, a, L);
+            hipLaunchKernelGGL((k_consume<false, TEX>), gridF, block, 0, stream, a, L);
         }
     }
-    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL(k_combine, gridC, block, 0, stream, a, L);
+    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
     return (int)hipGetLastError();
 }
 
@@ -853,8 +879,15 @@ int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed
 }
 
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
-    if (bvh_stack_needed <= 16) return launch_all<16>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 24) return launch_all<24>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 32) return launch_all<32>(args, n_tiles, stats, stream);
-    return launch_all<RTU_MAX_BVH_STACK>(args, n_tiles, stats, stream);
+    // textured scenes run their own instantiation: untextured ones carry no uvw and sample nothing
+    if (args.scene.textured) {
+        if (bvh_stack_needed <= 16) return launch_all<16, true>(args, n_tiles, stats, stream);
+        if (bvh_stack_needed <= 24) return launch_all<24, true>(args, n_tiles, stats, stream);
+        if (bvh_stack_needed <= 32) return launch_all<32, true>(args, n_tiles, stats, stream);
+        return launch_all<RTU_MAX_BVH_STACK, true>(args, n_tiles, stats, stream);
+    }
+    if (bvh_stack_needed <= 16) return launch_all<16, false>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 24) return launch_all<24, false>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 32) return launch_all<32, false>(args, n_tiles, stats, stream);
+    return launch_all<RTU_MAX_BVH_STACK, false>(args, n_tiles, stats, stream);
 }

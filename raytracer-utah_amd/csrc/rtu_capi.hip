@@ -35,6 +35,7 @@ struct RtuContext {
     uint32_t* defer_list = nullptr;
     uint32_t  defer_cap_s = 0;
     bool     any_recursive_material = true;
+    bool     textured = false;
     uint32_t n_meshes = 0;
     uint32_t nsl = 0;
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
@@ -400,9 +401,20 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
     if (s->n_lights && !s->lights) return fail(ctx, RTU_ERR_ARG, "lights is NULL");
     if (s->n_meshes && !s->meshes) return fail(ctx, RTU_ERR_ARG, "meshes is NULL");
     if (s->camera.dof != 0) return fail(ctx, RTU_ERR_STOCHASTIC, "depth of field is stochastic");
-    if (s->n_textures > 0 || s->material_maps || (s->background.has_map && !s->background.map_is_null) ||
-        (s->environment.has_map && !s->environment.map_is_null))
-        return fail(ctx, RTU_ERR_UNSUPPORTED, "textures (SURVEY row f2: loader and oracle support them, the device path not yet)");
+    for (uint32_t i = 0; i < s->n_textures; i++) {
+        const RtuTexture& t = s->textures[i];
+        if (t.type != RTU_TEX_FILE && t.type != RTU_TEX_CHECKER) return fail(ctx, RTU_ERR_ARG, "texture %u: unknown type", i);
+        if (t.type == RTU_TEX_FILE && (t.width < 0 || t.height < 0 || ((size_t)t.width * t.height > 0 && !t.rgb)))
+            return fail(ctx, RTU_ERR_ARG, "texture %u: bad image", i);
+    }
+    auto map_ok = [&](const RtuTexMap& m) { return !m.present || m.texture < (int32_t)s->n_textures; };
+    if (!map_ok(s->background_map) || !map_ok(s->environment_map)) return fail(ctx, RTU_ERR_ARG, "background/environment map: bad texture index");
+    if (s->material_maps)
+        for (uint32_t i = 0; i < s->n_materials * 4; i++)
+            if (!map_ok(s->material_maps[i])) return fail(ctx, RTU_ERR_ARG, "material map %u: bad texture index", i);
+    if (((s->background.has_map && !s->background.map_is_null) && !s->background_map.present) ||
+        ((s->environment.has_map && !s->environment.map_is_null) && !s->environment_map.present))
+        return fail(ctx, RTU_ERR_ARG, "textured background/environment without its texture map");
     for (uint32_t i = 0; i < s->n_lights; i++) {
         const RtuLight& l = s->lights[i];
         if (l.type < RTU_LIGHT_AMBIENT || l.type > RTU_LIGHT_POINT) return fail(ctx, RTU_ERR_ARG, "light %u: bad type", i);
@@ -510,7 +522,7 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
     size_t cap_s0 = ((tiles + RTU_SHARDS - 1) / RTU_SHARDS) * 64;
     size_t want[RTU_MAX_LEVELS];
     size_t maxcap = cap_s0;
-    bool fits = ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl;
+    bool fits = ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv);
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         want[L] = L == 0 || ctx->want_cap_s[L] < cap_s0 ? cap_s0 : ctx->want_cap_s[L];
         if (want[L] > maxcap) maxcap = want[L];
@@ -538,6 +550,10 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
         if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fpend, cap)) != RTU_OK) return rc;
+        if (ctx->textured) {
+            if ((rc = alloc_level(ctx, &lv.fuv, cap)) != RTU_OK) return rc;
+            if ((rc = alloc_level(ctx, &lv.fsuv, cap * 3)) != RTU_OK) return rc;
+        }
         if ((rc = alloc_level(ctx, &lv.lmain, cap)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.lrefl, cap)) != RTU_OK) return rc;
         lv.cap_s = (uint32_t)cap_s;
@@ -774,6 +790,12 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if ((rc = upload(ctx, m.v, (size_t)m.nv * 3, &d.v)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.fn, (size_t)m.nf * 3, &d.fn)) != RTU_OK) return rc;
         if ((rc = upload(ctx, m.vn, (size_t)m.nvn * 3, &d.vn)) != RTU_OK) return rc;
+        d.vt = nullptr;
+        d.ft = nullptr;
+        if (s->n_textures > 0 && m.vt && m.ft && m.nvt) {  // texture coordinates only travel with textured scenes
+            if ((rc = upload(ctx, m.vt, (size_t)m.nvt * 3, &d.vt)) != RTU_OK) return rc;
+            if ((rc = upload(ctx, m.ft, (size_t)m.nf * 3, &d.ft)) != RTU_OK) return rc;
+        }
         d.scale = 0.0f;
         for (int k = 0; k < 3; k++) d.scale = fmaxf(d.scale, fmaxf(fabsf(m.bound_min[k]), fabsf(m.bound_max[k])));
         memcpy(d.bmin, m.bound_min, sizeof d.bmin);
@@ -802,6 +824,31 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &ds.materials)) != RTU_OK) return rc;
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &ds.lights)) != RTU_OK) return rc;
     if ((rc = upload(ctx, meshes.data(), meshes.size(), &ds.meshes)) != RTU_OK) return rc;
+    // textures
+    ds.textured = (s->n_textures > 0) ? 1u : 0u;
+    if (ds.textured) {
+        std::vector<DevTexture> texs(s->n_textures);
+        for (uint32_t i = 0; i < s->n_textures; i++) {
+            const RtuTexture& t = s->textures[i];
+            DevTexture& o = texs[i];
+            memset(&o, 0, sizeof o);
+            o.type = t.type; o.width = t.width; o.height = t.height;
+            memcpy(o.color1, t.color1, sizeof o.color1);
+            memcpy(o.color2, t.color2, sizeof o.color2);
+            if (t.type == RTU_TEX_FILE && (size_t)t.width * t.height > 0)
+                if ((rc = upload(ctx, t.rgb, (size_t)t.width * t.height * 3, &o.rgb)) != RTU_OK) return rc;
+        }
+        if ((rc = upload(ctx, texs.data(), texs.size(), &ds.textures)) != RTU_OK) return rc;
+        if (s->material_maps)
+            if ((rc = upload(ctx, s->material_maps, (size_t)s->n_materials * 4, &ds.mat_maps)) != RTU_OK) return rc;
+        ds.bg_map = s->background_map;
+        ds.env_map = s->environment_map;
+    }
+    ds.bg = s->background;
+    ds.env = s->environment;
+    ds.img_w = s->camera.img_width;
+    ds.img_h = s->camera.img_height;
+    ctx->textured = ds.textured != 0;
     ds.n_nodes = s->n_nodes;
     ds.walk_stack_limit = 0xFFFFu;
     ds.n_lights = s->n_lights;

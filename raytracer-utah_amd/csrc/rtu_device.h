@@ -50,6 +50,8 @@ struct DevMesh {
     const float*    v;
     const uint32_t* fn;
     const float*    vn;
+    const uint32_t* ft;         // face -> 3 texture-vertex ids, or nullptr (then hits carry uvw = 0)
+    const float*    vt;
     float    bmin[3], bmax[3];
     uint32_t n_bvh_nodes, n_elements;
     uint32_t any_empty_box;     // some BVH box has min > max (cannot come from triangles)
@@ -69,11 +71,24 @@ struct DevNode {                // one scene-graph node (wave-uniform data)
     int32_t chain[RTU_MAX_NODE_DEPTH];  // chain[d] = ancestor at depth d (chain[depth] == self)
 };
 
+struct DevTexture {              // RtuTexture with the image in device memory
+    int32_t type, width, height, pad;
+    const uint8_t* rgb;
+    float color1[3], color2[3];
+};
+
 struct DevScene {
     const DevNode*     nodes;
     const RtuMaterial* materials;
     const RtuLight*    lights;
     const DevMesh*     meshes;
+    // textures; textured == 0: none of the following is read and hits carry no uvw
+    const DevTexture*  textures;
+    const RtuTexMap*   mat_maps;    // nullptr or 4 per material (RTU_MAP_*)
+    RtuTexMap bg_map, env_map;      // present only with a real texture
+    RtuEnvColor bg, env;
+    int32_t  img_w, img_h;          // camera.imgWidth / imgHeight: the background is sampled at (x/imgWidth, y/imgHeight)
+    uint32_t textured, pad_tex;
     uint32_t n_nodes, n_lights;
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
@@ -113,6 +128,8 @@ struct LevelBuffers {
     int4*   fchild;  // {main child, Fresnel child, mirror child, pending}
     float*  fsh;     // [cap * nsl] Shadow() of every non-ambient light
     float4* fslot;   // [cap * 3 * 2] closest hit of the three secondary rays: {p.xyz,z} {N.xyz,packed}
+    float4* fuv;     // textured scenes only: [cap] {hInfo.uvw, -} of the frame; [cap * 3] of the secondary hits
+    float4* fsuv;
     uint32_t* lmain; // [cap] per shard: the frames (index within the shard) that fire a refracted / TIR (and Fresnel) ray
     uint32_t* lrefl; // [cap] per shard: the frames that fire a mirror ray — k_trace visits these lists for the secondary slots
     uint32_t* fpend; // [cap] per shard: the frames (index within the shard) that wait for children — what k_combine visits

@@ -24,9 +24,9 @@ struct Ray {
     f3 p, dir;
 };
 
-struct Hit {  // HitInfo without uvw/duvw (no textures on this path) — scene.h:150-163
+struct Hit {  // HitInfo (scene.h:150-163); uvw is maintained for textured scenes only
     float z;
-    f3    p, N;
+    f3    p, N, uvw;
     int   node;
     bool  front;
 };
@@ -195,7 +195,7 @@ template <bool LITERAL> __device__ __forceinline__ bool le_001(float x) { return
 __device__ __forceinline__ bool gt_00001(float x) { return x > 0.00001f; }
 
 template <bool LITERAL>
-__device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h) {
+__device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h, bool tex = false) {
     if (LITERAL && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     float a = dot3(ray.dir, ray.dir);
     float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
@@ -235,10 +235,15 @@ __device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h) {
         f3 nn = norm3(temp);
         h.N = h.front ? nn : -nn;
         h.p = temp;
+        if (tex) {  // :38-41: atan2f / asinf in binary32, the rest in binary64
+            const float u = (float)(0.5 - (double)atan2f(h.N.x, h.N.y) / (2 * 3.14159265358979323846));
+            const float v = (float)(0.5 + (double)asinf(h.N.z) / 3.14159265358979323846);
+            h.uvw = mk3(u, v, 0);
+        }
     }
     return ret;
 }
-__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) { return sphere_hit_t<false>(ray, h); }
+__device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h, bool tex = false) { return sphere_hit_t<false>(ray, h, tex); }
 
 // Plane::IntersectRay (objFunctions.cpp:107-140). Fast form: the bounding-box test (:109) is
 // evaluated last and only when it can matter. The box is the unit square itself (z from 0 to 0),
@@ -248,7 +253,7 @@ __device__ __forceinline__ bool sphere_hit(const Ray& ray, Hit& h) { return sphe
 // rounding of q and of the slab bounds, <= 4 ulp * (1 + |p|): the box test is evaluated when q is
 // within 1e-5 * (1 + |p|) of an edge (40x reserve), otherwise it is known to pass.
 template <bool LITERAL>
-__device__ __forceinline__ bool plane_hit_t(const Ray& ray, Hit& h) {
+__device__ __forceinline__ bool plane_hit_t(const Ray& ray, Hit& h, bool tex = false) {
     if (LITERAL && !box_hit(ray, mk3(-1, -1, 0), mk3(1, 1, 0), RTU_BIGFLOAT)) return false;
     if (ray.dir.z != 0) {
         float t = (-ray.p.z) / (ray.dir.z);
@@ -263,13 +268,14 @@ __device__ __forceinline__ bool plane_hit_t(const Ray& ray, Hit& h) {
                 h.N = mk3(0, 0, h.front ? 1.0f : -1.0f);
                 h.z = t;
                 h.p = mk3(q.x, q.y, 0);
+                if (tex) h.uvw = mk3((q.x + 1) / 2, (q.y + 1) / 2, 0);  // :131
                 return true;
             }
         }
     }
     return false;
 }
-__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h) { return plane_hit_t<false>(ray, h); }
+__device__ __forceinline__ bool plane_hit(const Ray& ray, Hit& h, bool tex = false) { return plane_hit_t<false>(ray, h, tex); }
 
 // Point2::Cross (cyPoint.h:247-249)
 __device__ __forceinline__ float cross2(float ax, float ay, float bx, float by) { return (-ay) * bx + ax * by; }
@@ -465,6 +471,7 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
         const uint32_t face = elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
+        h.uvw = mesh.vt ? interp(mesh.vt, mesh.ft + 3 * face, win.bc) : mk3(0, 0, 0);  // GetTexCoord, objFunctions.cpp:320
     }
     return hitResult;
 }
@@ -602,6 +609,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
         const uint32_t face = mesh.fast.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
+        h.uvw = mesh.vt ? interp(mesh.vt, mesh.ft + 3 * face, win.bc) : mk3(0, 0, 0);  // GetTexCoord, objFunctions.cpp:320
     }
     return hitResult;
 }
@@ -774,6 +782,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
         const uint32_t face = mesh.fast.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
+        h.uvw = mesh.vt ? interp(mesh.vt, mesh.ft + 3 * face, win.bc) : mk3(0, 0, 0);  // GetTexCoord, objFunctions.cpp:320
     }
     return hitResult;
 }
@@ -793,7 +802,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 // the bounding box of a mesh node the walk is abandoned and `deferred` is set; the caller
 // queues the ray for the narrow-wavefront stage-2 kernel, which walks the whole scene
 // again with DEFER=false. Rays that never touch a mesh complete in stage 1.
-template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false>
+template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
                                       const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
@@ -827,8 +836,8 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         Ray lr = to_node(n, pr);
         RTU_CNT(node);
         bool hit;
-        if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h);
-        else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h);
+        if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h, TEX);
+        else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h, TEX);
         else if (DEFER) {
             const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
             if (box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) deferred = true;
@@ -857,6 +866,78 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         for (int j = best; j >= 0; j = gn[j].parent) from_node(gn[j], h);
     }
     return any;
+}
+
+// ---------------------------------------------------------------------------
+// Textures: Texture::TileClamp (scene.h:354-365), TextureFile::Sample bilinear with
+// tiling (texture.cpp:95-121), TextureChecker::Sample (:125-133), TextureMap::Sample (scene.h:382),
+// TexturedColor::Sample / SampleEnvironment (:421-431). Point sampling: the reference's Shade()
+// calls Sample(hInfo.uvw) without derivatives. Same float operations as the reference; only
+// atan2f / asinf (sphere uv, environment direction) are the device library's.
+__device__ __forceinline__ f3 tile_clamp(f3 uvw) {
+    f3 u = mk3(uvw.x - (float)(int)uvw.x, uvw.y - (float)(int)uvw.y, uvw.z - (float)(int)uvw.z);
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+__device__ __forceinline__ f3 c24(const uint8_t* p) { return mk3((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f); }
+__device__ __forceinline__ f3 texture_sample(const DevTexture& t, f3 uvw) {
+    const f3 u = tile_clamp(uvw);
+    if (t.type == RTU_TEX_CHECKER) {
+        const f3 c1 = ld3(t.color1), c2 = ld3(t.color2);
+        if (u.x <= 0.5f) return u.y <= 0.5f ? c1 : c2;
+        return u.y <= 0.5f ? c2 : c1;
+    }
+    const int width = t.width, height = t.height;
+    if (width + height == 0) return mk3(0, 0, 0);
+    const float x = (float)width * u.x, y = (float)height * u.y;
+    int ix = (int)x, iy = (int)y;
+    const float fx = x - (float)ix, fy = y - (float)iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1;
+    if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1;
+    if (iyp >= height) iyp -= height;
+    const uint8_t* d = t.rgb;
+    return ((c24(d + 3 * ((size_t)iy * width + ix)) * ((1 - fx) * (1 - fy)) + c24(d + 3 * ((size_t)iy * width + ixp)) * (fx * (1 - fy))) +
+            c24(d + 3 * ((size_t)iyp * width + ix)) * ((1 - fx) * fy)) +
+           c24(d + 3 * ((size_t)iyp * width + ixp)) * (fx * fy);
+}
+__device__ __forceinline__ f3 map_sample(const DevScene& s, const RtuTexMap& m, f3 uvw) {
+    if (m.texture < 0) return mk3(0, 0, 0);
+    return texture_sample(s.textures[m.texture], mat_mul(m.itm, uvw - ld3(m.pos)));  // TransformTo, scene.h:235
+}
+// TexturedColor::Sample of material colour k (RTU_MAP_*) of material mtl
+template <bool TEX>
+__device__ __forceinline__ f3 mtl_color(const DevScene& s, int mtl, int k, f3 color, f3 uvw) {
+    if (!TEX || !s.mat_maps) return color;
+    const RtuTexMap& m = s.mat_maps[4 * mtl + k];
+    return m.present ? color * map_sample(s, m, uvw) : color;
+}
+__device__ __forceinline__ f3 env_color_sample(const DevScene& s, const RtuEnvColor& e, const RtuTexMap& m, f3 uvw) {
+    const f3 c = ld3(e.color);
+    if (!e.has_map) return c;
+    if (e.map_is_null || !m.present) return c * mk3(0, 0, 0);
+    return c * map_sample(s, m, uvw);
+}
+// background.Sample(Point3(x/imgWidth, y/imgHeight, 0)), RenderFunctions.cpp:145
+template <bool TEX>
+__device__ __forceinline__ f3 background_sample(const DevScene& s, int x, int y) {
+    if (!TEX) return ld3(s.background);
+    return env_color_sample(s, s.bg, s.bg_map, mk3((float)x / (float)s.img_w, (float)y / (float)s.img_h, 0));
+}
+// environment.SampleEnvironment(dir), scene.h:425-431
+__device__ __forceinline__ f3 env_sample(const DevScene& s, f3 dir) {
+    if (!s.env.has_map) return ld3(s.environment);
+    const float z = asinf(-dir.z) / 3.14159265358979323846f + 0.5f;
+    const float den = (float)((double)fabsf(dir.x) + (double)fabsf(dir.y));  // fabs() of a float promotes to double
+    const float x = dir.x / den, y = dir.y / den;
+    const f3 uvw = mk3(0.5f, 0.5f, 0.0f) + (mk3(0.5f, 0.5f, 0) * x + mk3(-0.5f, 0.5f, 0) * y) * z;
+    return env_color_sample(s, s.env, s.env_map, uvw);
 }
 
 // sampledNormal of mtlFunctions.cpp:162-165 / :275-277 with SampleSphere(...,0) == (0,0,0)

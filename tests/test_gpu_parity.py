@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import ALL_TAGS, FULL_TAGS, SMALL_TAGS, sha256
+from conftest import ALL_TAGS, FULL_TAGS, SMALL_TAGS, TEX_TAGS, sha256
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,25 @@ def test_device_render_and_timing_entry(pkg, ctx, golden):
     ref, _ = ctx.render(fr)
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
     pkg.hip.rtu_device_free(ctx._h, d)
+
+
+@pytest.mark.parametrize("tag", TEX_TAGS)
+@pytest.mark.parametrize("size", [None, (800, 600)])
+def test_textured_scene(pkg, orc, ctx, golden, tag, size):
+    """SURVEY row f2 — Project7: checkerboards on a plane and a sphere, a PNG on the teapot (through its
+    texture vertices), PNG background and environment maps, mirror and glass. z bit-exact; counters
+    equal; RGB within the bar against the oracle (pinned bit-exact to the reference on this scene)."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    W, H = size or (g.width, g.height)
+    gpu, gstats = render_gpu(pkg, ctx, scene, W, H)
+    fast, _ = render_gpu(pkg, ctx, scene, W, H, stats=False)
+    assert np.array_equal(gpu.view(np.uint32), fast.view(np.uint32)), "fast and counting variants differ"
+    cpu, cstats = orc.render(scene, W, H, threads=8)
+    check_against(gpu, cpu, orc)
+    assert gstats == cstats
+    if size is None:
+        assert sha256(gpu[..., 3]) == g.meta["sha256_z_f32"]
 
 
 def test_full_size_properties(pkg, ctx, golden):

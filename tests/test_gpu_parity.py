@@ -141,6 +141,69 @@ def test_textured_scene(pkg, orc, ctx, golden, tag, size):
         assert sha256(gpu[..., 3]) == g.meta["sha256_z_f32"]
 
 
+@pytest.mark.parametrize("coop", [True, False])
+def test_textured_synthetic_scene(pkg, orc, ctx, tmp_path, coop):
+    """Textures on every TexturedColor of a material (diffuse, specular, reflection, refraction), with
+    rotated / scaled / translated TextureMaps, a PPM file texture on a mesh through its texture
+    vertices, a checker background under a transform and a file environment map seen through glass
+    and by mirror rays. GPU against the oracle (whose texture code is pinned to the reference)."""
+    import math, random
+    rnd = random.Random(11)
+    Wt, Ht = 33, 17
+    (tmp_path / "noise.ppm").write_bytes(b"P6\n%d %d\n255\n" % (Wt, Ht) + bytes(rnd.randrange(256) for _ in range(Wt * Ht * 3)))
+    # a bumpy disc with texture vertices
+    verts, tverts, faces = [(0.0, 0.0, 0.3)], [(0.5, 0.5, 0.0)], []
+    n = 48
+    for i in range(n):
+        a = 2 * math.pi * i / n
+        verts.append((3 * math.cos(a), 3 * math.sin(a), 0.2 * math.sin(5 * a)))
+        tverts.append((0.5 + 0.5 * math.cos(a), 0.5 + 0.5 * math.sin(a), 0.0))
+    for i in range(n):
+        faces.append((1, 2 + i, 2 + (i + 1) % n))
+    with open(tmp_path / "disc.obj", "w") as f:
+        for v in verts: f.write("v %r %r %r\n" % v)
+        for t in tverts: f.write("vt %r %r %r\n" % t)
+        f.write("vn 0 0 1\n")
+        for (i, j, k) in faces: f.write("f %d/%d/1 %d/%d/1 %d/%d/1\n" % (i, i, j, j, k, k))
+    xml = tmp_path / "tex.xml"
+    xml.write_text("""<xml><scene>
+      <background r="0.9" g="0.8" b="1" texture="checkerboard"><color1 r="0.1" g="0.2" b="0.3"/><color2 r="0.9" g="0.9" b="0.7"/>
+        <scale x="0.2" y="0.1"/><rotate angle="20" z="1"/></background>
+      <environment value="0.8" texture="{d}/noise.ppm"><scale value="0.5"/></environment>
+      <object type="plane" name="floor" material="floor"><scale value="30"/><translate z="-2"/></object>
+      <object type="obj" name="{d}/disc.obj" material="disc"><rotate angle="25" x="1"/><translate x="-2" y="1" z="0.5"/></object>
+      <object type="sphere" name="glass" material="glass"><scale value="1.6"/><translate x="2.5" y="-1" z="0.4"/></object>
+      <object type="sphere" name="ball" material="ball"><scale value="1.2"/><translate x="0" y="3" z="0"/></object>
+      <material type="blinn" name="floor"><diffuse r="1" g="1" b="1" texture="checkerboard"><color1 r="0.2" g="0.2" b="0.2"/><color2 r="0.8" g="0.7" b="0.6"/>
+          <scale value="0.05"/><rotate angle="30" z="1"/></diffuse><specular value="0.2"/><glossiness value="20"/>
+        <reflection value="0.5" texture="checkerboard"><color1 r="0" g="0" b="0"/><color2 r="1" g="1" b="1"/><scale value="0.25"/></reflection></material>
+      <material type="blinn" name="disc"><diffuse texture="{d}/noise.ppm"><translate x="0.25" y="0.1"/></diffuse>
+        <specular r="1" g="1" b="1" texture="{d}/noise.ppm"><scale value="3"/></specular><glossiness value="35"/></material>
+      <material type="blinn" name="glass"><diffuse value="0.05"/><specular value="0.9"/><glossiness value="90"/>
+        <refraction index="1.45" value="0.9" texture="checkerboard"><color1 r="0.6" g="0.9" b="0.6"/><color2 r="1" g="1" b="1"/><scale x="0.1" y="0.2"/></refraction></material>
+      <material type="blinn" name="ball"><diffuse r="0.9" g="0.9" b="0.9" texture="{d}/noise.ppm"><scale x="0.5" y="1"/><rotate angle="45" z="1"/></diffuse>
+        <specular value="0.5"/><glossiness value="50"/><reflection value="0.3"/></material>
+      <light type="ambient" name="a"><intensity value="0.2"/></light>
+      <light type="direct" name="d"><intensity value="0.6"/><direction x="-0.4" y="0.5" z="-1"/></light>
+      <light type="point" name="p"><intensity value="0.5"/><position x="6" y="-8" z="9"/></light>
+    </scene><camera><position x="1" y="-13" z="5"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="45"/>
+      <width value="240"/><height value="160"/></camera></xml>""".format(d=tmp_path))
+    scene = pkg.Scene.from_xml(str(xml))
+    assert scene.desc.n_textures == 5  # four checkerboards + the PPM (one texture, shared by name)
+    W, H = 240, 160
+    ctx.upload(scene)
+    fr = pkg.frame_setup(scene.desc.camera, W, H)
+    fr.coop_threshold = 10 ** 9 if coop else 1
+    fast, _ = ctx.render(fr)
+    cnt, gst = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+    cpu, cst = orc.render(scene, W, H, threads=4)
+    assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast and counting variants differ"
+    check_against(fast, cpu, orc)
+    assert gst == cst
+    assert gst["secondary_rays"] > 5000 and gst["mesh_entries"] > 2000
+    assert len(np.unique((np.clip(fast[..., :3], 0, 1) * 255).astype(np.uint8).reshape(-1, 3), axis=0)) > 2000  # textures visible
+
+
 def test_full_size_properties(pkg, ctx, golden):
     """Size-independent properties at the BASELINE resolution: misses carry BIGFLOAT and
     the background colour, hits have 0 < z < BIGFLOAT, re-rendering is idempotent."""

@@ -238,3 +238,82 @@ def test_float_thresholds_equal_the_double_literals():
         assert np.array_equal(xd > 0.001, xs >= c)
         assert np.array_equal(xd <= 0.001, xs < c)
         assert np.array_equal(xd > 0.00001, xs > e)
+
+
+def _png_bytes(w, h, ctype, pixels, palette=None):
+    """Minimal PNG writer for the decoder test: 8-bit, colour types 0/2/3/4/6, filter 0..4 cycling."""
+    import struct, zlib
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    raw = bytearray()
+    prev = bytes(w * ch)
+    for y in range(h):
+        row = bytes(pixels[y * w * ch:(y + 1) * w * ch])
+        f = y % 5
+        out = bytearray()
+        for x in range(w * ch):
+            a = row[x - ch] if x >= ch else 0
+            b = prev[x]
+            c = prev[x - ch] if x >= ch else 0
+            if f == 0: pred = 0
+            elif f == 1: pred = a
+            elif f == 2: pred = b
+            elif f == 3: pred = (a + b) // 2
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out.append((row[x] - pred) & 0xFF)
+        raw += bytes([f]) + out
+        prev = row
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    comp = zlib.compress(bytes(raw))
+    data += chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    return data
+
+
+def test_texture_files_decode(pkg, tmp_path):
+    """TextureFile::Load through the host library's own PNG (grey, RGB, palette, grey+alpha, RGBA; all
+    five filters; split IDAT) and binary PPM readers: the RtuTexture holds exactly the RGB the
+    reference's lodepng::decode(..., LCT_RGB) / LoadPPM would hold."""
+    import ctypes, random, struct
+    rnd = random.Random(3)
+    W, H = 7, 6
+    cases = {}
+    grey = [rnd.randrange(256) for _ in range(W * H)]
+    cases["g.png"] = (_png_bytes(W, H, 0, grey), [v for g_ in grey for v in (g_, g_, g_)])
+    rgb = [rnd.randrange(256) for _ in range(W * H * 3)]
+    cases["c.png"] = (_png_bytes(W, H, 2, rgb), rgb)
+    pal = [rnd.randrange(256) for _ in range(5 * 3)]
+    idx = [rnd.randrange(5) for _ in range(W * H)]
+    cases["p.png"] = (_png_bytes(W, H, 3, idx, pal), [pal[3 * i + k] for i in idx for k in range(3)])
+    ga = [rnd.randrange(256) for _ in range(W * H * 2)]
+    cases["ga.png"] = (_png_bytes(W, H, 4, ga), [ga[2 * i] for i in range(W * H) for _ in range(3)])
+    rgba = [rnd.randrange(256) for _ in range(W * H * 4)]
+    cases["a.png"] = (_png_bytes(W, H, 6, rgba), [rgba[4 * i + k] for i in range(W * H) for k in range(3)])
+    cases["x.ppm"] = (b"P6\n# a comment\n%d %d\n255\n" % (W, H) + bytes(rgb), rgb)
+    for name, (data, want) in cases.items():
+        (tmp_path / name).write_bytes(data)
+        xml = tmp_path / "t.xml"
+        xml.write_text("""<xml><scene>
+          <object type="plane" name="p" material="m"/>
+          <material type="blinn" name="m"><diffuse texture="%s"/></material>
+        </scene><camera><position x="0" y="0" z="5"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="40"/>
+          <width value="16"/><height value="16"/></camera></xml>""" % (tmp_path / name))
+        sc = pkg.Scene.from_xml(str(xml))  # keeps the desc alive
+        d = sc.desc
+        assert d.n_textures == 1, name
+        hdr = ctypes.string_at(d.textures, 56)
+        typ, w, h, _ = struct.unpack_from("<4i", hdr, 0)
+        ptr = struct.unpack_from("<Q", hdr, 16)[0]
+        assert (typ, w, h) == (0, W, H), name
+        assert list(ctypes.string_at(ptr, W * H * 3)) == want, name
+    # a file that cannot be decoded behaves like a missing one: TextureMap(NULL), the colour turns black
+    (tmp_path / "bad.png").write_bytes(b"not a png")
+    xml.write_text(xml.read_text().replace(str(tmp_path / name), str(tmp_path / "bad.png")))
+    sc = pkg.Scene.from_xml(str(xml))
+    d = sc.desc
+    assert d.n_textures == 0 and not d.material_maps

@@ -66,8 +66,8 @@ typedef struct RtuNode {
     int32_t reserved[5];
 } RtuNode;
 
-/* MtlBlinn parameters (untextured colours; texture ids are reserved for the
- * "next" row f2 and must be -1). 96 bytes. */
+/* MtlBlinn parameters: the plain colours of its TexturedColors; texture maps on them live in
+ * RtuSceneDesc.material_maps (a map multiplies the colour, scene.h:421). 96 bytes. */
 typedef struct RtuMaterial {
     float   diffuse[3];
     float   specular[3];

@@ -38,7 +38,7 @@ extern "C" {
 #define RTU_OK               0
 #define RTU_ERR_ARG         (-1)  /* NULL / out-of-range argument */
 #define RTU_ERR_HIP         (-2)  /* a HIP runtime call failed (see rtu_last_error) */
-#define RTU_ERR_UNSUPPORTED (-3)  /* scene exceeds a device-path limit or uses textures */
+#define RTU_ERR_UNSUPPORTED (-3)  /* scene exceeds a device-path limit */
 #define RTU_ERR_STOCHASTIC  (-4)  /* soft shadows / glossy bounces / depth of field */
 #define RTU_ERR_NO_SCENE    (-5)  /* render before rtu_upload_scene */
 #define RTU_ERR_NO_DEVICE   (-6)  /* no such GPU */

@@ -14,7 +14,7 @@ extern "C" {
 
 #define RTU_ORACLE_ERR_ARG         (-1)
 #define RTU_ORACLE_ERR_STOCHASTIC  (-2) /* soft shadows / glossy / dof: reference is non-deterministic */
-#define RTU_ORACLE_ERR_UNSUPPORTED (-3) /* textures etc.: outside the restated scope */
+#define RTU_ORACLE_ERR_UNSUPPORTED (-3) /* outside the restated scope */
 
 /* Same fields, same meaning as RtuStats in rtu_render.h, so CPU and GPU ray and
  * traversal counters can be compared exactly. */

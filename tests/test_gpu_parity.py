@@ -35,7 +35,7 @@ def render_gpu(pkg, ctx, scene, W, H, stats=True, shard_count=1):
     return pkg.assemble(shards, frames, H), allstats
 
 
-def check_against(gpu, ref_rgbz, orc):
+def check_against(gpu, ref_rgbz, orc, rel_tol=RGB_REL_TOL):
     zbad = int((gpu[..., 3].view(np.uint32) != ref_rgbz[..., 3].view(np.uint32)).sum())
     assert zbad == 0, "%d pixels differ in float z" % zbad
     g8, _, gz8 = orc.postprocess(gpu)
@@ -45,7 +45,7 @@ def check_against(gpu, ref_rgbz, orc):
     assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
     a, b = gpu[..., :3].astype(np.float64), ref_rgbz[..., :3].astype(np.float64)
     rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
-    assert rel.max() <= RGB_REL_TOL, "linear RGB relative error %.3g" % rel.max()
+    assert rel.max() <= rel_tol, "linear RGB relative error %.3g" % rel.max()
     return int((d8 > 0).sum())
 
 

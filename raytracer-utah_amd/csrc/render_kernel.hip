@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
             const f3 diffuse = mtl_color<TEX>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
             const f3 specular = mtl_color<TEX>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
             uint32_t j = 0;  // index among the non-ambient lights
+            const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
             for (uint32_t i = 0; i < s.n_lights; i++) {
                 const RTU_CONST RtuLight& l = as_const(s.lights)[i];
                 const f3 intensity = ld3(l.intensity);
@@ -601,7 +602,6 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
                     direct = direct + diffuse * intensity;  // :132
                     continue;
                 }
-                const f3 viewDirection = norm3(cam_pos - p);  // :137
                 const f3 lvec = ld3(l.vec);
                 const bool isDirect = l.type == RTU_LIGHT_DIRECT;
                 const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
@@ -625,64 +625,110 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
         }
 
         // ---- secondary-ray hits become frames of the next level ----
+        // Every append below is one atomic per wavefront whose result the wavefront has to wait for,
+        // so they are batched: ONE append for the child frames of all three slots, then the appends to
+        // the slot lists and the pending list together (three round trips to L2 instead of ten).
         int st[3] = {RTU_CH_NONE, RTU_CH_NONE, RTU_CH_NONE};
         float bz = 0.0f;
         bool bfront = true;
+        float4 s0[3], s1[3];
+        uint32_t packed[3];
+        bool spawn[3], slotAct[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             bool slotActive = false;
             if (active) {
                 if (k == SLOT_MAIN) slotActive = (info & RTU_FI_MAIN) != 0;
-                else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (st[SLOT_MAIN] >= 0 || st[SLOT_MAIN] == RTU_CH_WHITE);
+                else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (packed[SLOT_MAIN] & 1u);  // :234: the refracted ray hit
                 else slotActive = (info & RTU_FI_C) != 0;
             }
-            float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
-            uint32_t packed = 0;
+            s0[k] = make_float4(0, 0, 0, 0);
+            s1[k] = s0[k];
+            packed[k] = 0;
             if (slotActive) {
                 const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
-                s0 = slotp[0];
-                s1 = slotp[1];
-                packed = __float_as_uint(s1.w);
+                s0[k] = slotp[0];
+                s1[k] = slotp[1];
+                packed[k] = __float_as_uint(s1[k].w);
             }
-            const bool hit = slotActive && (packed & 1u);
-            const int cmid = (int)(packed >> 2) - 1;
-            const bool spawn = hit && cmid >= 0 && haveNext;
-            if (k == SLOT_MAIN && hit) { bz = s0.w; bfront = (packed & 2u) != 0; }
-            const uint32_t cshard = c % RTU_SHARDS;
-            const uint32_t cfl = wave_append(&a.fcnt->n_frames[Ln][cshard], spawn);  // all 64 lanes take part
-            uint32_t cinfo = 0;
-            bool made = false;
-            if (slotActive) {
-                if (!hit) st[k] = RTU_CH_MISS;
-                else if (cmid < 0) st[k] = RTU_CH_WHITE;
-                else if (spawn && cfl < nx.cap_s) {
-                    const uint32_t idx = cfl + cshard * nx.cap_s;
-                    // the child Shade(): ray direction, hit point and normal of the secondary ray
-                    const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
-                    const f3 cp = mk3(s0.x, s0.y, s0.z), cN = mk3(s1.x, s1.y, s1.z);
-                    f3 cuvw = mk3(0, 0, 0);
-                    if (TEX) {
-                        const float4 t = lv.fsuv[(size_t)f * 3 + k];
-                        cuvw = mk3(t.x, t.y, t.z);
-                        nx.fuv[idx] = t;
-                    }
-                    cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed & 2u) != 0, cdir, cp, cN, cuvw);
-                    nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-                    nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
-                    nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0.w);
-                    st[k] = (int)idx;
-                    made = true;
-                } else {
-                    a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
-                    st[k] = RTU_CH_MISS;
+            slotAct[k] = slotActive;
+            const bool hit = slotActive && (packed[k] & 1u);
+            spawn[k] = hit && (int)(packed[k] >> 2) - 1 >= 0 && haveNext;
+            if (k == SLOT_MAIN && hit) { bz = s0[k].w; bfront = (packed[k] & 2u) != 0; }
+        }
+        const uint32_t cshard = c % RTU_SHARDS;
+        // child frame indices: slot 0's children of the wavefront, then slot 1's, then slot 2's
+        uint32_t cfl[3];
+        {
+            const unsigned long long m0 = __ballot(spawn[0]), m1 = __ballot(spawn[1]), m2 = __ballot(spawn[2]);
+            const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+            uint32_t base = 0;
+            if (n0 + n1 + n2) {
+                if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][cshard], n0 + n1 + n2);
+                base = (uint32_t)__shfl((int)base, 0);
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            cfl[0] = base + (uint32_t)__popcll(m0 & below);
+            cfl[1] = base + n0 + (uint32_t)__popcll(m1 & below);
+            cfl[2] = base + n0 + n1 + (uint32_t)__popcll(m2 & below);
+        }
+        bool wantMain[3] = {false, false, false}, wantRefl[3] = {false, false, false};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (!slotAct[k]) continue;
+            const bool hit = (packed[k] & 1u) != 0;
+            const int cmid = (int)(packed[k] >> 2) - 1;
+            if (!hit) st[k] = RTU_CH_MISS;
+            else if (cmid < 0) st[k] = RTU_CH_WHITE;
+            else if (spawn[k] && cfl[k] < nx.cap_s) {
+                const uint32_t idx = cfl[k] + cshard * nx.cap_s;
+                // the child Shade(): ray direction, hit point and normal of the secondary ray
+                const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
+                const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
+                f3 cuvw = mk3(0, 0, 0);
+                if (TEX) {
+                    const float4 t = lv.fsuv[(size_t)f * 3 + k];
+                    cuvw = mk3(t.x, t.y, t.z);
+                    nx.fuv[idx] = t;
                 }
+                const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw);
+                nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
+                nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
+                nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
+                st[k] = (int)idx;
+                wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
+                wantRefl[k] = (cinfo & RTU_FI_C) != 0;
+            } else {
+                a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
+                st[k] = RTU_CH_MISS;
             }
-            if (haveNext) list_frame(a, Ln, cshard, made, cinfo, cfl);
         }
         const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
-        {  // frames that wait for children go on the shard's list for k_combine (never more than frames)
-            const uint32_t pi = wave_append(&a.fcnt->n_pending[L][shard], pending);
-            if (pending) lv.fpend[(size_t)shard * lv.cap_s + pi] = fl;
+        {  // the new frames join the slot lists of their level (list_frame); this frame the pending list of its own
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long a0 = __ballot(wantMain[0]), a1 = __ballot(wantMain[1]), a2 = __ballot(wantMain[2]);
+            const unsigned long long c0 = __ballot(wantRefl[0]), c1 = __ballot(wantRefl[1]), c2 = __ballot(wantRefl[2]);
+            const unsigned long long pm = __ballot(pending);
+            const uint32_t na = (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2)), nc = (uint32_t)(__popcll(c0) + __popcll(c1) + __popcll(c2));
+            uint32_t ba = 0, bc = 0, bp = 0;
+            if (lane == 0) {  // independent atomics: issued back to back, one wait
+                if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][cshard], na);
+                if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][cshard], nc);
+                if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][shard], (uint32_t)__popcll(pm));
+            }
+            ba = (uint32_t)__shfl((int)ba, 0);
+            bc = (uint32_t)__shfl((int)bc, 0);
+            bp = (uint32_t)__shfl((int)bp, 0);
+            const unsigned long long am[3] = {a0, a1, a2}, cm[3] = {c0, c1, c2};
+            uint32_t oa = ba, oc = bc;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (wantMain[k]) nx.lmain[(size_t)cshard * nx.cap_s + oa + (uint32_t)__popcll(am[k] & below)] = cfl[k];
+                if (wantRefl[k]) nx.lrefl[(size_t)cshard * nx.cap_s + oc + (uint32_t)__popcll(cm[k] & below)] = cfl[k];
+                oa += (uint32_t)__popcll(am[k]);
+                oc += (uint32_t)__popcll(cm[k]);
+            }
+            if (pending) lv.fpend[(size_t)shard * lv.cap_s + bp + (uint32_t)__popcll(pm & below)] = fl;
         }
         if (!active) continue;
         if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);

@@ -201,11 +201,51 @@ __device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h, bool tex = 
     float b = 2 * dot3(ray.p - mk3(0, 0, 0), ray.dir);
     float c = dot3(ray.p, ray.p) - 1;
     float sqrtCheck = b * b - 4 * a * c;
-    if (!LITERAL && !(sqrtCheck >= 0)) return false;
+    if (!LITERAL) {
+        // Branch-light form for a 64-wide wavefront (measured: half of the stage-1 kernels' vector
+        // instructions were moves, selects and compares around per-lane branches). The decision
+        // tree of :28-:99 is symmetric in (m, n): with lo / hi the smaller / larger root it reads
+        //   m == n         : hit at m            if m < h.z and m >= 0.001
+        //   m != n, ordered: "hit" (ret)         if lo < h.z and (lo >= 0.001 or hi >= 0.001)
+        //                    h.z = hi (back face) if lo <= 0.001 < hi < h.z; h.z = lo (front) if lo > 0.001;
+        //                    else h.z and h.front stay as they were — the stale fall-through
+        // evaluated here as predicates; one wave-uniform early exit, one rare box test.
+        bool cand = sqrtCheck >= 0;
+        if (!__any(cand)) return false;
+        const float sq = sqrtf(sqrtCheck);
+        const float m = (-b + sq) / (2 * a);
+        const float n = (-b - sq) / (2 * a);
+        const bool needBox = cand && !(sq > 4e-3f * fabsf(b));
+        if (__any(needBox)) {
+            const bool bh = box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT);
+            cand = cand && (!needBox || bh);
+        }
+        const bool lt = m < n, ordered = lt || n < m;
+        const float lo = lt ? m : n, hi = lt ? n : m;
+        const bool retEq = m == n && m < h.z && ge_001<false>(m);
+        const bool condB = ordered && lo < h.z && (ge_001<false>(lo) || ge_001<false>(hi));
+        const bool takeHi = condB && le_001<false>(lo) && gt_001<false>(hi) && hi < h.z;
+        const bool takeLo = condB && !takeHi && gt_001<false>(lo);
+        const bool ret = cand && (retEq || condB);
+        if (ret) {
+            if (retEq) { h.z = m; h.front = true; }
+            else if (takeHi) { h.z = hi; h.front = false; }
+            else if (takeLo) { h.z = lo; h.front = true; }
+            f3 temp = ray.p + ray.dir * h.z;  // h.z may be stale: reproduced on purpose
+            f3 nn = norm3(temp);
+            h.N = h.front ? nn : -nn;
+            h.p = temp;
+            if (tex) {  // :38-41: atan2f / asinf in binary32, the rest in binary64
+                const float u = (float)(0.5 - (double)atan2f(h.N.x, h.N.y) / (2 * 3.14159265358979323846));
+                const float v = (float)(0.5 + (double)asinf(h.N.z) / 3.14159265358979323846);
+                h.uvw = mk3(u, v, 0);
+            }
+        }
+        return ret;
+    }
     float sq = sqrtf(sqrtCheck);
     float m = (-b + sq) / (2 * a);
     float n = (-b - sq) / (2 * a);
-    if (!LITERAL && !(sq > 4e-3f * fabsf(b)) && !box_hit(ray, mk3(-1, -1, -1), mk3(1, 1, 1), RTU_BIGFLOAT)) return false;
     bool ret = false;
     if (m == n && m < h.z && ge_001<LITERAL>(m)) {
         h.z = m;
@@ -235,11 +275,6 @@ __device__ __forceinline__ bool sphere_hit_t(const Ray& ray, Hit& h, bool tex = 
         f3 nn = norm3(temp);
         h.N = h.front ? nn : -nn;
         h.p = temp;
-        if (tex) {  // :38-41: atan2f / asinf in binary32, the rest in binary64
-            const float u = (float)(0.5 - (double)atan2f(h.N.x, h.N.y) / (2 * 3.14159265358979323846));
-            const float v = (float)(0.5 + (double)asinf(h.N.z) / 3.14159265358979323846);
-            h.uvw = mk3(u, v, 0);
-        }
     }
     return ret;
 }

@@ -128,22 +128,6 @@ __device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bo
     return info;
 }
 
-// A new frame of level L (index fl within its shard) joins the lists of the frames that fire
-// secondary rays, so that k_trace visits the secondary slots only where there is a ray.
-// Wave-uniform: must be reached by all 64 lanes.
-__device__ __forceinline__ void list_frame(const KernelArgs& a, int L, uint32_t shard, bool made, uint32_t info, uint32_t fl) {
-    const LevelBuffers& lv = a.lv[L];
-    const bool m = made && (info & RTU_FI_MAIN), c = made && (info & RTU_FI_C);
-    if (__any(m)) {
-        const uint32_t i = wave_append(&a.fcnt->n_lmain[L][shard], m);
-        if (m) lv.lmain[(size_t)shard * lv.cap_s + i] = fl;
-    }
-    if (__any(c)) {
-        const uint32_t i = wave_append(&a.fcnt->n_lrefl[L][shard], c);
-        if (c) lv.lrefl[(size_t)shard * lv.cap_s + i] = fl;
-    }
-}
-
 __device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Init, scene.h:162
     h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
 }
@@ -234,24 +218,41 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             }
         }
     }
-    const uint32_t fl = wave_append(&a.fcnt->n_frames[0][shard], want);
+    // the frame's info word first, then its three appends (frame array, the two slot lists) issued
+    // back to back: one wait for the wavefront instead of three
     uint32_t info = 0;
-    bool made = false;
+    if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw);
+    const LevelBuffers& lv = a.lv[0];
+    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+    const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
+    const unsigned long long mf = __ballot(want), mm = __ballot(wm), mc = __ballot(wc);
+    uint32_t bf = 0, bm = 0, bc = 0;
+    if (mf) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
+        if ((threadIdx.x & 63u) == leader) {
+            bf = atomicAdd(&a.fcnt->n_frames[0][shard], (uint32_t)__popcll(mf));
+            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][shard], (uint32_t)__popcll(mm));
+            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][shard], (uint32_t)__popcll(mc));
+        }
+        bf = (uint32_t)__shfl((int)bf, (int)leader);
+        bm = (uint32_t)__shfl((int)bm, (int)leader);
+        bc = (uint32_t)__shfl((int)bc, (int)leader);
+    }
     if (want) {
-        const LevelBuffers& lv = a.lv[0];
+        const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
         if (fl < lv.cap_s) {
             const uint32_t idx = fl + shard * lv.cap_s;
-            info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw);
             if (TEX) lv.fuv[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
             lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
-            made = true;
+            // list entries of a frame beyond the capacity are harmless: the frame is rendered again
+            if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
+            if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
         } else {
             a.fcnt->overflow = 1;
         }
     }
-    list_frame(a, 0, shard, made, info, fl);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
             }
         }
         const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
-        {  // the new frames join the slot lists of their level (list_frame); this frame the pending list of its own
+        {  // the new frames join the slot lists of their level — the lists of the frames that fire a refracted / mirror ray, so that k_trace visits the secondary slots only where there is a ray —; this frame the pending list of its own
             const unsigned long long below = (1ull << lane) - 1ull;
             const unsigned long long a0 = __ballot(wantMain[0]), a1 = __ballot(wantMain[1]), a2 = __ballot(wantMain[2]);
             const unsigned long long c0 = __ballot(wantRefl[0]), c1 = __ballot(wantRefl[1]), c2 = __ballot(wantRefl[2]);

@@ -130,6 +130,13 @@ int  rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgb
  * Returns the number of values written. */
 int  rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_us_out);
 
+/* Test hook for the tail kernel. Recursion levels that were almost empty in the previous frame of a
+ * scene are not launched kernel by kernel in the next one: one kernel evaluates every frame of the
+ * first such level, subtree and all, with one wavefront per frame. Which level that is
+ * comes from the previous frame's counts and is only a hint — any value renders the same image.
+ * This sets it for the next frame: 3..5, or 6 for "no tail". */
+int  rtu_debug_tail_from(RtuContext* ctx, int level);
+
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
  * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would
  * need more is finished on the reference's tree — on any scene. Results must not change. */

@@ -120,7 +120,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -136,6 +136,7 @@ _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
+_sig(hip, "rtu_debug_tail_from", _I, _P, _I)
 _sig(hip, "rtu_timeline_exits", _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double))
 _sig(hip, "rtu_mesh_info", _I, _P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32))
 _sig(hip, "rtu_frame_counts", _I, _P, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
@@ -294,6 +295,7 @@ class Context:
     TIMELINE_SLOTS = (["k_primary", "k_primary2c", "k_primary2"] +
                       ["%s(L%d)" % (k, L) for L in range(6) for k in ("k_trace", "k_trace2c", "k_trace2", "k_consume")] +
                       ["k_combine(L%d)" % L for L in range(6)])
+    # when the tail kernel (k_tail) takes over from level Ls, its stamps are in the k_trace(L<Ls>) slot
 
     def render_timeline(self, frame, d_ptr):
         """One frame with in-kernel GPU-clock stamps: [(kernel, start_us, end_us)] in launch order."""

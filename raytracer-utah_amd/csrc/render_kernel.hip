@@ -559,198 +559,246 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
     return result;
 }
 
+// One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
+// lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
+// a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
 template <bool STATS, bool TEX>
-__global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
+__device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
+                                              uint32_t f, int st_out[3]) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const bool haveNext = L + 1 < RTU_MAX_LEVELS;
     const int Ln = haveNext ? L + 1 : L;
     const LevelBuffers& nx = a.lv[Ln];
-    const uint32_t lane = threadIdx.x;
     const f3 cam_pos = ld3(a.frame.cam_pos);
+    st_out[0] = st_out[1] = st_out[2] = RTU_CH_NONE;
+    float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
+    if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
+    const uint32_t info = __float_as_uint(fa.w);
+    const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+    const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
+    const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
+    f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
+    if (TEX && active) {
+        const float4 t = lv.fuv[f];
+        uvw = mk3(t.x, t.y, t.z);
+    }
+
+    // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
+    f3 direct = mk3(0, 0, 0);
+    if (active && (info & RTU_FI_SH)) {
+        const int mtl = (int)(info & RTU_FI_MTL_MASK);
+        const f3 diffuse = mtl_color<TEX>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
+        const f3 specular = mtl_color<TEX>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
+        uint32_t j = 0;  // index among the non-ambient lights
+        const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
+        for (uint32_t i = 0; i < s.n_lights; i++) {
+            const RTU_CONST RtuLight& l = as_const(s.lights)[i];
+            const f3 intensity = ld3(l.intensity);
+            if (l.type == RTU_LIGHT_AMBIENT) {
+                direct = direct + diffuse * intensity;  // :132
+                continue;
+            }
+            const f3 lvec = ld3(l.vec);
+            const bool isDirect = l.type == RTU_LIGHT_DIRECT;
+            const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
+            const f3 lightDirection = norm3(-ldir);                       // :138
+            const f3 halfVector = norm3(viewDirection + lightDirection);  // :139
+            float NDotL = dot3(N, lightDirection);
+            float NDotH = dot3(N, halfVector);
+            if (NDotL < 0.0f) NDotL = 0.0f;
+            if (NDotH < 0.0f) NDotH = 0.0f;
+            const float sh = lv.fsh[(size_t)f * a.nsl + j];
+            j++;
+            f3 illum;
+            if (isDirect) {
+                illum = intensity * sh;  // lights.h:48
+            } else {
+                const f3 d = lvec - p;
+                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
+            }
+            direct = direct + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
+        }
+    }
+
+    // ---- secondary-ray hits become frames of the next level ----
+    // Every append below is one atomic per wavefront whose result the wavefront has to wait for,
+    // so they are batched: ONE append for the child frames of all three slots, then the appends to
+    // the slot lists and the pending list together (three round trips to L2 instead of ten).
+    int st[3] = {RTU_CH_NONE, RTU_CH_NONE, RTU_CH_NONE};
+    float bz = 0.0f;
+    bool bfront = true;
+    float4 s0[3], s1[3];
+    uint32_t packed[3];
+    bool spawn[3], slotAct[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        bool slotActive = false;
+        if (active) {
+            if (k == SLOT_MAIN) slotActive = (info & RTU_FI_MAIN) != 0;
+            else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (packed[SLOT_MAIN] & 1u);  // :234: the refracted ray hit
+            else slotActive = (info & RTU_FI_C) != 0;
+        }
+        s0[k] = make_float4(0, 0, 0, 0);
+        s1[k] = s0[k];
+        packed[k] = 0;
+        if (slotActive) {
+            const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
+            s0[k] = slotp[0];
+            s1[k] = slotp[1];
+            packed[k] = __float_as_uint(s1[k].w);
+        }
+        slotAct[k] = slotActive;
+        const bool hit = slotActive && (packed[k] & 1u);
+        spawn[k] = hit && (int)(packed[k] >> 2) - 1 >= 0 && haveNext;
+        if (k == SLOT_MAIN && hit) { bz = s0[k].w; bfront = (packed[k] & 2u) != 0; }
+    }
+    // child frame indices: slot 0's children of the wavefront, then slot 1's, then slot 2's
+    uint32_t cfl[3];
+    {
+        const unsigned long long m0 = __ballot(spawn[0]), m1 = __ballot(spawn[1]), m2 = __ballot(spawn[2]);
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+        uint32_t base = 0;
+        if (n0 + n1 + n2) {
+            if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][cshard], n0 + n1 + n2);
+            base = (uint32_t)__shfl((int)base, 0);
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        cfl[0] = base + (uint32_t)__popcll(m0 & below);
+        cfl[1] = base + n0 + (uint32_t)__popcll(m1 & below);
+        cfl[2] = base + n0 + n1 + (uint32_t)__popcll(m2 & below);
+    }
+    bool wantMain[3] = {false, false, false}, wantRefl[3] = {false, false, false};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!slotAct[k]) continue;
+        const bool hit = (packed[k] & 1u) != 0;
+        const int cmid = (int)(packed[k] >> 2) - 1;
+        if (!hit) st[k] = RTU_CH_MISS;
+        else if (cmid < 0) st[k] = RTU_CH_WHITE;
+        else if (spawn[k] && cfl[k] < nx.cap_s) {
+            const uint32_t idx = cfl[k] + cshard * nx.cap_s;
+            // the child Shade(): ray direction, hit point and normal of the secondary ray
+            const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
+            const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
+            f3 cuvw = mk3(0, 0, 0);
+            if (TEX) {
+                const float4 t = lv.fsuv[(size_t)f * 3 + k];
+                cuvw = mk3(t.x, t.y, t.z);
+                nx.fuv[idx] = t;
+            }
+            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw);
+            nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
+            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
+            nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
+            st[k] = (int)idx;
+            wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
+            wantRefl[k] = (cinfo & RTU_FI_C) != 0;
+        } else {
+            a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
+            st[k] = RTU_CH_MISS;
+        }
+    }
+    const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
+    st_out[0] = st[0]; st_out[1] = st[1]; st_out[2] = st[2];
+    {  // the new frames join the slot lists of their level — the lists of the frames that fire a refracted / mirror ray, so that k_trace visits the secondary slots only where there is a ray —; this frame the pending list of its own
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long a0 = __ballot(wantMain[0]), a1 = __ballot(wantMain[1]), a2 = __ballot(wantMain[2]);
+        const unsigned long long c0 = __ballot(wantRefl[0]), c1 = __ballot(wantRefl[1]), c2 = __ballot(wantRefl[2]);
+        const unsigned long long pm = __ballot(pending);
+        const uint32_t na = (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2)), nc = (uint32_t)(__popcll(c0) + __popcll(c1) + __popcll(c2));
+        uint32_t ba = 0, bc = 0, bp = 0;
+        if (lane == 0) {  // independent atomics: issued back to back, one wait
+            if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][cshard], na);
+            if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][cshard], nc);
+            if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][shard], (uint32_t)__popcll(pm));
+        }
+        ba = (uint32_t)__shfl((int)ba, 0);
+        bc = (uint32_t)__shfl((int)bc, 0);
+        bp = (uint32_t)__shfl((int)bp, 0);
+        const unsigned long long am[3] = {a0, a1, a2}, cm[3] = {c0, c1, c2};
+        uint32_t oa = ba, oc = bc;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (wantMain[k]) nx.lmain[(size_t)cshard * nx.cap_s + oa + (uint32_t)__popcll(am[k] & below)] = cfl[k];
+            if (wantRefl[k]) nx.lrefl[(size_t)cshard * nx.cap_s + oc + (uint32_t)__popcll(cm[k] & below)] = cfl[k];
+            oa += (uint32_t)__popcll(am[k]);
+            oc += (uint32_t)__popcll(cm[k]);
+        }
+        if (pending) lv.fpend[(size_t)shard * lv.cap_s + bp + (uint32_t)__popcll(pm & below)] = fl;
+    }
+    if (!active) return;
+    if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
+    if (!pending) {
+        const f3 one = mk3(1, 1, 1);
+        const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw);
+        if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+        else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+    } else {
+        lv.fres[f] = make_float4(direct.x, direct.y, direct.z, 0.0f);  // the direct term waits for the children
+    }
+}
+
+template <bool STATS, bool TEX>
+__global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
+    const LevelBuffers& lv = a.lv[L];
+    const uint32_t lane = threadIdx.x;
     const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t fl = k * 64u + lane;
         const bool active = fl < shard_count(a, L, shard);
-        const uint32_t f = shard * lv.cap_s + fl;
-        float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
-        if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
-        const uint32_t info = __float_as_uint(fa.w);
-        const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-        const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
-        const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
-        f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
-        if (TEX && active) {
-            const float4 t = lv.fuv[f];
-            uvw = mk3(t.x, t.y, t.z);
-        }
-
-        // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
-        f3 direct = mk3(0, 0, 0);
-        if (active && (info & RTU_FI_SH)) {
-            const int mtl = (int)(info & RTU_FI_MTL_MASK);
-            const f3 diffuse = mtl_color<TEX>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
-            const f3 specular = mtl_color<TEX>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
-            uint32_t j = 0;  // index among the non-ambient lights
-            const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
-            for (uint32_t i = 0; i < s.n_lights; i++) {
-                const RTU_CONST RtuLight& l = as_const(s.lights)[i];
-                const f3 intensity = ld3(l.intensity);
-                if (l.type == RTU_LIGHT_AMBIENT) {
-                    direct = direct + diffuse * intensity;  // :132
-                    continue;
-                }
-                const f3 lvec = ld3(l.vec);
-                const bool isDirect = l.type == RTU_LIGHT_DIRECT;
-                const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
-                const f3 lightDirection = norm3(-ldir);                       // :138
-                const f3 halfVector = norm3(viewDirection + lightDirection);  // :139
-                float NDotL = dot3(N, lightDirection);
-                float NDotH = dot3(N, halfVector);
-                if (NDotL < 0.0f) NDotL = 0.0f;
-                if (NDotH < 0.0f) NDotH = 0.0f;
-                const float sh = lv.fsh[(size_t)f * a.nsl + j];
-                j++;
-                f3 illum;
-                if (isDirect) {
-                    illum = intensity * sh;  // lights.h:48
-                } else {
-                    const f3 d = lvec - p;
-                    illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
-                }
-                direct = direct + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
-            }
-        }
-
-        // ---- secondary-ray hits become frames of the next level ----
-        // Every append below is one atomic per wavefront whose result the wavefront has to wait for,
-        // so they are batched: ONE append for the child frames of all three slots, then the appends to
-        // the slot lists and the pending list together (three round trips to L2 instead of ten).
-        int st[3] = {RTU_CH_NONE, RTU_CH_NONE, RTU_CH_NONE};
-        float bz = 0.0f;
-        bool bfront = true;
-        float4 s0[3], s1[3];
-        uint32_t packed[3];
-        bool spawn[3], slotAct[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            bool slotActive = false;
-            if (active) {
-                if (k == SLOT_MAIN) slotActive = (info & RTU_FI_MAIN) != 0;
-                else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (packed[SLOT_MAIN] & 1u);  // :234: the refracted ray hit
-                else slotActive = (info & RTU_FI_C) != 0;
-            }
-            s0[k] = make_float4(0, 0, 0, 0);
-            s1[k] = s0[k];
-            packed[k] = 0;
-            if (slotActive) {
-                const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
-                s0[k] = slotp[0];
-                s1[k] = slotp[1];
-                packed[k] = __float_as_uint(s1[k].w);
-            }
-            slotAct[k] = slotActive;
-            const bool hit = slotActive && (packed[k] & 1u);
-            spawn[k] = hit && (int)(packed[k] >> 2) - 1 >= 0 && haveNext;
-            if (k == SLOT_MAIN && hit) { bz = s0[k].w; bfront = (packed[k] & 2u) != 0; }
-        }
-        const uint32_t cshard = c % RTU_SHARDS;
-        // child frame indices: slot 0's children of the wavefront, then slot 1's, then slot 2's
-        uint32_t cfl[3];
-        {
-            const unsigned long long m0 = __ballot(spawn[0]), m1 = __ballot(spawn[1]), m2 = __ballot(spawn[2]);
-            const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-            uint32_t base = 0;
-            if (n0 + n1 + n2) {
-                if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][cshard], n0 + n1 + n2);
-                base = (uint32_t)__shfl((int)base, 0);
-            }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            cfl[0] = base + (uint32_t)__popcll(m0 & below);
-            cfl[1] = base + n0 + (uint32_t)__popcll(m1 & below);
-            cfl[2] = base + n0 + n1 + (uint32_t)__popcll(m2 & below);
-        }
-        bool wantMain[3] = {false, false, false}, wantRefl[3] = {false, false, false};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (!slotAct[k]) continue;
-            const bool hit = (packed[k] & 1u) != 0;
-            const int cmid = (int)(packed[k] >> 2) - 1;
-            if (!hit) st[k] = RTU_CH_MISS;
-            else if (cmid < 0) st[k] = RTU_CH_WHITE;
-            else if (spawn[k] && cfl[k] < nx.cap_s) {
-                const uint32_t idx = cfl[k] + cshard * nx.cap_s;
-                // the child Shade(): ray direction, hit point and normal of the secondary ray
-                const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
-                const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
-                f3 cuvw = mk3(0, 0, 0);
-                if (TEX) {
-                    const float4 t = lv.fsuv[(size_t)f * 3 + k];
-                    cuvw = mk3(t.x, t.y, t.z);
-                    nx.fuv[idx] = t;
-                }
-                const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw);
-                nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-                nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
-                nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
-                st[k] = (int)idx;
-                wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
-                wantRefl[k] = (cinfo & RTU_FI_C) != 0;
-            } else {
-                a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
-                st[k] = RTU_CH_MISS;
-            }
-        }
-        const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
-        {  // the new frames join the slot lists of their level — the lists of the frames that fire a refracted / mirror ray, so that k_trace visits the secondary slots only where there is a ray —; this frame the pending list of its own
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long a0 = __ballot(wantMain[0]), a1 = __ballot(wantMain[1]), a2 = __ballot(wantMain[2]);
-            const unsigned long long c0 = __ballot(wantRefl[0]), c1 = __ballot(wantRefl[1]), c2 = __ballot(wantRefl[2]);
-            const unsigned long long pm = __ballot(pending);
-            const uint32_t na = (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2)), nc = (uint32_t)(__popcll(c0) + __popcll(c1) + __popcll(c2));
-            uint32_t ba = 0, bc = 0, bp = 0;
-            if (lane == 0) {  // independent atomics: issued back to back, one wait
-                if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][cshard], na);
-                if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][cshard], nc);
-                if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][shard], (uint32_t)__popcll(pm));
-            }
-            ba = (uint32_t)__shfl((int)ba, 0);
-            bc = (uint32_t)__shfl((int)bc, 0);
-            bp = (uint32_t)__shfl((int)bp, 0);
-            const unsigned long long am[3] = {a0, a1, a2}, cm[3] = {c0, c1, c2};
-            uint32_t oa = ba, oc = bc;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (wantMain[k]) nx.lmain[(size_t)cshard * nx.cap_s + oa + (uint32_t)__popcll(am[k] & below)] = cfl[k];
-                if (wantRefl[k]) nx.lrefl[(size_t)cshard * nx.cap_s + oc + (uint32_t)__popcll(cm[k] & below)] = cfl[k];
-                oa += (uint32_t)__popcll(am[k]);
-                oc += (uint32_t)__popcll(cm[k]);
-            }
-            if (pending) lv.fpend[(size_t)shard * lv.cap_s + bp + (uint32_t)__popcll(pm & below)] = fl;
-        }
-        if (!active) continue;
-        if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
-        if (!pending) {
-            const f3 one = mk3(1, 1, 1);
-            const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw);
-            if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-            else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
-        } else {
-            lv.fres[f] = make_float4(direct.x, direct.y, direct.z, 0.0f);  // the direct term waits for the children
-        }
+        int st[3];
+        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st);
     }
 }
 
 // Frames that waited for children: combine bottom-up.
+// One frame that waited for its children (the body of k_combine; also used by k_tail).
 template <bool TEX>
-__global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
-    const Stamp stamp(a, RTU_TL_COMBINE0 + L);
+__device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32_t f) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
+    const float4 fa = lv.fa[f];
+    const uint32_t info = __float_as_uint(fa.w);
+    const int4 ch = lv.fchild[f];
+    const float4 fb = lv.fb[f], fc = lv.fc[f], fr = lv.fres[f];
+    const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
+    const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
+    const int st[3] = {ch.x, ch.y, ch.z};
+    f3 ret[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ret[k] = mk3(1, 1, 1);
+        if (st[k] >= 0) {
+            const float4 r = nx.fres[st[k]];
+            ret[k] = mk3(r.x, r.y, r.z);
+        }
+    }
+    float bz = 0.0f;
+    bool bfront = true;
+    if ((info & RTU_FI_MAIN) && !(info & RTU_FI_TIR)) {
+        const float4* slotp = lv.fslot + ((size_t)f * 3 + SLOT_MAIN) * 2;
+        bz = slotp[0].w;
+        bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
+    }
+    f3 uvw = mk3(0, 0, 0);
+    if (TEX) {
+        const float4 t = lv.fuv[f];
+        uvw = mk3(t.x, t.y, t.z);
+    }
+    const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw);
+    if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+    else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+}
+
+template <bool TEX>
+__global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
+    const Stamp stamp(a, RTU_TL_COMBINE0 + L);
+    const LevelBuffers& lv = a.lv[L];
     // only the frames k_consume listed as waiting for children
     uint32_t pmax = a.fcnt->n_pending[L][lane_id() % RTU_SHARDS];
 #pragma unroll
@@ -764,43 +812,88 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
         const uint32_t e = k * 64u + threadIdx.x;
         if (e >= a.fcnt->n_pending[L][shard]) continue;
         const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
-        const float4 fa = lv.fa[f];
-        const uint32_t info = __float_as_uint(fa.w);
-        const int4 ch = lv.fchild[f];
-        const float4 fb = lv.fb[f], fc = lv.fc[f], fr = lv.fres[f];
-        const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-        const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
-        const int st[3] = {ch.x, ch.y, ch.z};
-        f3 ret[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            ret[k] = mk3(1, 1, 1);
-            if (st[k] >= 0) {
-                const float4 r = nx.fres[st[k]];
-                ret[k] = mk3(r.x, r.y, r.z);
-            }
-        }
-        float bz = 0.0f;
-        bool bfront = true;
-        if ((info & RTU_FI_MAIN) && !(info & RTU_FI_TIR)) {
-            const float4* slotp = lv.fslot + ((size_t)f * 3 + SLOT_MAIN) * 2;
-            bz = slotp[0].w;
-            bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
-        }
-        f3 uvw = mk3(0, 0, 0);
-        if (TEX) {
-            const float4 t = lv.fuv[f];
-            uvw = mk3(t.x, t.y, t.z);
-        }
-        const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw);
-        if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-        else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+        combine_frame<TEX>(a, L, f);
     }
 }
 
 // Self-test of the exact-division identity used by the slab and barycentric tests
 // (rtu_intersect.h, fdiv): pseudo-random bit patterns (all exponents, subnormals, zeros,
 // infinities, NaNs) plus same-exponent pairs; counts quotients whose bits differ from `/`.
+// ------------------------------------------------------------------------------------
+// THE TAIL. Deep recursion levels are often almost empty (two frames per level from level 3 on in
+// the headline scene) yet each costs four dependent launches (~4 us apiece, whatever their size)
+// plus a k_combine. When the previous frame showed that level Ls and below are small, the host
+// launches none of their kernels but this one: ONE WAVEFRONT PER FRAME of level Ls evaluates that
+// frame's whole Shade() subtree (levels Ls..max) — the same phases, the same device functions on
+// the same global frame arrays, sequenced inside the wavefront: rays eight at a time (one 8-lane
+// group each, cooperative BVH walk), consume with one lane per frame, children collected in LDS,
+// then the combines bottom-up. Correct for any number of frames (the count is only a hint for
+// the host's choice); the regular k_combine of levels < Ls follow.
+template <bool TEX>
+__global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
+    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * Ls);
+    __shared__ uint32_t s_stack[8 * RTU_STACK8];
+    __shared__ uint32_t s_cur[RTU_MAX_LEVELS][64];  // my frames of each level (at most 3^(L-Ls) <= 27: the host keeps Ls >= 3)
+    __shared__ uint32_t s_n[RTU_MAX_LEVELS];
+    __shared__ uint8_t s_pend[RTU_MAX_LEVELS][64];  // the frame waits for children (fchild is only written for frames with secondary rays)
+    const uint32_t lane = threadIdx.x, grp = lane >> 3;
+    const bool leader = (lane & 7u) == 0;
+    const int levels = a.frame.max_bounce + 1;
+    const uint32_t nslots = a.nsl + 3u;
+    const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
+    const uint32_t roots = level_max_count(a, Ls) * RTU_SHARDS;  // (index within shard, shard) slots
+    Counters cnt = {};
+    for (uint32_t c = blockIdx.x; c < roots; c += gridDim.x) {
+        const uint32_t shard = c % RTU_SHARDS, rfl = c / RTU_SHARDS;
+        if (rfl >= shard_count(a, Ls, shard)) continue;  // wave-uniform
+        uint32_t n = 1;
+        if (lane == 0) {
+            s_cur[Ls][0] = shard * a.lv[Ls].cap_s + rfl;
+            s_n[Ls] = 1;
+        }
+        int last = Ls;
+        for (int L = Ls; L < levels && n > 0; L++) {
+            last = L;
+            __threadfence();  // s_cur and the frame records of this level are written
+            // ---- the rays of my frames: eight at a time, one 8-lane group each
+            const uint32_t total = n * nslots;
+            for (uint32_t base = 0; base < total; base += 8u) {
+                const uint32_t item = base + grp;
+                if (item < total) {
+                    const uint32_t i = item / nslots, slot = item - i * nslots;
+                    frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, slot, s_cur[L][i], s_stack + grp, cnt, leader, 8u, nullptr);
+                }
+            }
+            __threadfence();  // shadow results and secondary hits are visible to the consuming lanes
+            // ---- consume: one lane per frame; its children become my frames of the next level
+            const bool active = lane < n;
+            const uint32_t f = active ? s_cur[L][lane] : 0u;
+            int st[3];
+            consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st);
+            s_pend[L][lane] = (active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0)) ? 1 : 0;
+            uint32_t nn = 0;
+            if (L + 1 < levels) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const bool has = active && st[k] >= 0;
+                    const unsigned long long m = __ballot(has);
+                    if (has) s_cur[L + 1][nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)st[k];
+                    nn += (uint32_t)__popcll(m);
+                }
+                if (lane == 0) s_n[L + 1] = nn;
+            }
+            n = nn;
+        }
+        // ---- combine bottom-up what waited for children (levels Ls .. last-1)
+        for (int L = last - 1; L >= Ls; L--) {
+            __threadfence();
+            const uint32_t nL = s_n[L];
+            if (lane < nL && s_pend[L][lane]) combine_frame<TEX>(a, L, s_cur[L][lane]);
+        }
+        __threadfence();
+    }
+}
+
 __global__ void k_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches) {
     unsigned long long bad = 0;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n_pairs;
@@ -893,7 +986,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
         }
     }
-    for (int L = 0; L < levels; L++) {
+    // levels >= tail_from are evaluated by k_tail (fast variant only; the host passes tail_from >= 3, or 6 for none)
+    const int regular = (!stats && a.tail_from >= 3 && a.tail_from < levels) ? a.tail_from : levels;
+    for (int L = 0; L < regular; L++) {
         const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
             hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
@@ -909,7 +1004,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_consume<false, TEX>), gridF, block, 0, stream, a, L);
         }
     }
-    for (int L = levels - 2; L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
+    if (regular < levels) hipLaunchKernelGGL((k_tail<TEX>), dim3(1024), block, 0, stream, a, regular);
+    for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
     return (int)hipGetLastError();
 }
 

@@ -36,6 +36,10 @@ struct RtuContext {
     uint32_t  defer_cap_s = 0;
     bool     any_recursive_material = true;
     bool     textured = false;
+    // k_tail: the recursion level from which the previous frame of this scene was almost empty (a hint —
+    // any value renders the same image); last_tail_from: what the most recent frame was launched with
+    int      tail_hint = RTU_MAX_LEVELS, last_tail_from = RTU_MAX_LEVELS;
+    bool     last_stats = false;
     uint32_t n_meshes = 0;
     uint32_t nsl = 0;
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
@@ -590,6 +594,9 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
+    a.tail_from = stats ? RTU_MAX_LEVELS : ctx->tail_hint;
+    ctx->last_tail_from = a.tail_from;
+    ctx->last_stats = stats;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
     hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -597,6 +604,23 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 }
 
 // After the stream has drained: did any recursion level run out of frame capacity?
+// Frames per level of the frame just finished -> where k_tail may take over in the next one.
+void learn_tail(RtuContext* ctx, const FrameCounters& h) {
+    const uint32_t kTailMax = 2048;  // frames of the cut level: one wavefront each
+    uint32_t frames[RTU_MAX_LEVELS];
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        frames[L] = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) frames[L] += h.n_frames[L][s];
+    }
+    const int used = ctx->last_tail_from;  // levels > used were not materialised: their counts are unknown (zero)
+    const int top = used < RTU_MAX_LEVELS ? used : RTU_MAX_LEVELS - 1;
+    int hint = RTU_MAX_LEVELS;
+    for (int L = 3; L <= top; L++)
+        if (frames[L] <= kTailMax) { hint = L; break; }
+    if (hint == RTU_MAX_LEVELS && used < RTU_MAX_LEVELS) hint = used + 1 < RTU_MAX_LEVELS ? used + 1 : RTU_MAX_LEVELS;
+    ctx->tail_hint = hint;
+}
+
 // The append counters keep counting past the capacity, so an overflowed frame tells how much its
 // first overflowing level really needs (deeper levels may need another round: their parents were
 // dropped). Wanted capacities grow to the reported counts (+25 %, at least x2 for the level below).
@@ -604,7 +628,10 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     FrameCounters h;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     *overflow = h.overflow != 0;
-    if (!*overflow) return RTU_OK;
+    if (!*overflow) {
+        learn_tail(ctx, h);
+        return RTU_OK;
+    }
     bool grew = false;
     for (int L = 1; L < RTU_MAX_LEVELS; L++) {
         uint32_t need = 0;
@@ -860,6 +887,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
     memset(ctx->want_cap_s, 0, sizeof ctx->want_cap_s);
     ctx->want_defer_s = 0;
+    ctx->tail_hint = RTU_MAX_LEVELS;
     ctx->n_meshes = s->n_meshes;
     ctx->mesh_info = mesh_info;
     ctx->any_recursive_material = false;
@@ -939,6 +967,9 @@ int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     RTU_HIP(ctx, hipDeviceSynchronize());
     static_assert(sizeof(RtuStats) == 11 * sizeof(unsigned long long), "RtuStats layout");
     RTU_HIP(ctx, hipMemcpy(stats, ctx->counters, sizeof(RtuStats), hipMemcpyDeviceToHost));
+    FrameCounters h;
+    RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
+    if (!h.overflow) learn_tail(ctx, h);
     return RTU_OK;
 }
 
@@ -1004,6 +1035,11 @@ int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, vo
     }
     RTU_HIP(ctx, hipEventRecord(ctx->ev1, st));
     RTU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    {
+        bool overflow = false;
+        if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
+        if (overflow) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity; time the frame again");
+    }
     float ms = 0;
     RTU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms_out = ms / (float)iters;
@@ -1026,6 +1062,11 @@ int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz
     ctx->stamp_next = false;
     if (rc != RTU_OK) return rc;
     RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        bool overflow = false;
+        if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;  // also learns where the tail kernel may take over
+        if (overflow) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity; render the frame again");
+    }
     std::vector<unsigned long long> h(n);
     RTU_HIP(ctx, hipMemcpy(h.data(), ctx->tl, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     int khz = 0;
@@ -1066,6 +1107,12 @@ int rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_u
     for (uint32_t j = 64; j < RTU_TL_STRIDE && n < max_values; j++)
         if (h[j]) exit_us_out[n++] = (double)(h[j] - t0) * 1e3 / (double)khz;
     return n;
+}
+
+int rtu_debug_tail_from(RtuContext* ctx, int level) {
+    if (!ctx || level < 3 || level > RTU_MAX_LEVELS) return RTU_ERR_ARG;
+    ctx->tail_hint = level;
+    return RTU_OK;
 }
 
 int rtu_debug_walk_stack_limit(RtuContext* ctx, uint32_t entries) {

@@ -181,7 +181,7 @@ struct KernelArgs {
     uint32_t     nsl;               // number of non-ambient lights
     int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
     uint32_t     n_meshes;
-    uint32_t     pad1;
+    int32_t      tail_from;         // recursion levels >= this are evaluated by k_tail (RTU_MAX_LEVELS: none)
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine

@@ -703,7 +703,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
     const float4* tris = mesh.fast.tri;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sub = lane & 7u;
-    const uint32_t ldsN = mesh.lds_nodes, ldsOff = mesh.lds_off;
+    const uint32_t ldsN = lds_nodes ? mesh.lds_nodes : 0u, ldsOff = mesh.lds_off;  // lds_nodes == nullptr: nothing staged
     const FastRay fr = fast_ray(ray, mesh.scale);
     bool hitResult = false;
     TriWin win;

@@ -459,6 +459,23 @@ def test_frame_capacity_overflow_is_detected_and_repaired(pkg, orc, tmp_path):
         ctx2.close()
 
 
+@pytest.mark.parametrize("tag", ["p4_240x135", "teapot2_240x135", "p13_200x150", "p7_200x150"])
+@pytest.mark.parametrize("level", [3, 4, 5])
+def test_tail_kernel_any_cut_level(pkg, ctx, golden, tag, level):
+    """Recursion levels >= `level` evaluated by k_tail (one wavefront per frame of that level, its
+    whole Shade() subtree inside the wavefront) instead of the per-level kernels: the same image bit
+    for bit whatever the cut level and however many frames it holds (p4: tens of thousands)."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    fr = pkg.frame_setup(scene.desc.camera, g.width, g.height)
+    assert pkg.hip.rtu_debug_tail_from(ctx._h, 6) == 0
+    ref, _ = ctx.render(fr)
+    assert pkg.hip.rtu_debug_tail_from(ctx._h, level) == 0
+    tail, _ = ctx.render(fr)
+    assert np.array_equal(ref.view(np.uint32), tail.view(np.uint32))
+
+
 @pytest.mark.parametrize("tag,coop", [("teapot2_240x135", True), ("teapot2_240x135", False), ("p11_240x135", False)])
 def test_walk_stack_overflow_falls_back_to_the_reference_tree(pkg, ctx, golden, tag, coop):
     """A walk of the 4-wide / 8-wide tree that would need more stack than it has finishes on the

@@ -134,7 +134,7 @@ int  rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_
  * scene are not launched kernel by kernel in the next one: one kernel evaluates every frame of the
  * first such level, subtree and all, with one wavefront per frame. Which level that is
  * comes from the previous frame's counts and is only a hint — any value renders the same image.
- * This sets it for the next frame: 3..5, or 6 for "no tail". */
+ * This sets it for the next frame: 1..5, or 6 for "no tail". */
 int  rtu_debug_tail_from(RtuContext* ctx, int level);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on

@@ -829,13 +829,14 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
 // group each, cooperative BVH walk), consume with one lane per frame, children collected in LDS,
 // then the combines bottom-up. Correct for any number of frames (the count is only a hint for
 // the host's choice); the regular k_combine of levels < Ls follow.
+#define RTU_TAIL_CAP 256  // frames of one level in one subtree: at most 3^4 = 81 for a cut at level 1, 243 in theory
 template <bool TEX>
 __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * Ls);
     __shared__ uint32_t s_stack[8 * RTU_STACK8];
-    __shared__ uint32_t s_cur[RTU_MAX_LEVELS][64];  // my frames of each level (at most 3^(L-Ls) <= 27: the host keeps Ls >= 3)
+    __shared__ uint32_t s_cur[RTU_MAX_LEVELS][RTU_TAIL_CAP];  // my frames of each level
     __shared__ uint32_t s_n[RTU_MAX_LEVELS];
-    __shared__ uint8_t s_pend[RTU_MAX_LEVELS][64];  // the frame waits for children (fchild is only written for frames with secondary rays)
+    __shared__ uint8_t s_pend[RTU_MAX_LEVELS][RTU_TAIL_CAP];  // the frame waits for children (fchild is only written for frames with secondary rays)
     const uint32_t lane = threadIdx.x, grp = lane >> 3;
     const bool leader = (lane & 7u) == 0;
     const int levels = a.frame.max_bounce + 1;
@@ -865,30 +866,39 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
                 }
             }
             __threadfence();  // shadow results and secondary hits are visible to the consuming lanes
-            // ---- consume: one lane per frame; its children become my frames of the next level
-            const bool active = lane < n;
-            const uint32_t f = active ? s_cur[L][lane] : 0u;
-            int st[3];
-            consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st);
-            s_pend[L][lane] = (active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0)) ? 1 : 0;
+            // ---- consume: one lane per frame, 64 at a time; the children become my frames of the next level
             uint32_t nn = 0;
-            if (L + 1 < levels) {
+            for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+                const uint32_t i = b0 + lane;
+                const bool active = i < n;
+                const uint32_t f = active ? s_cur[L][i] : 0u;
+                int st[3];
+                consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st);
+                if (active) s_pend[L][i] = (st[0] >= 0 || st[1] >= 0 || st[2] >= 0) ? 1 : 0;
+                if (L + 1 < levels) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const bool has = active && st[k] >= 0;
-                    const unsigned long long m = __ballot(has);
-                    if (has) s_cur[L + 1][nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)st[k];
-                    nn += (uint32_t)__popcll(m);
+                    for (int k = 0; k < 3; k++) {
+                        const bool has = active && st[k] >= 0;
+                        const unsigned long long m = __ballot(has);
+                        const uint32_t at = nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (has) {
+                            if (at < (uint32_t)RTU_TAIL_CAP) s_cur[L + 1][at] = (uint32_t)st[k];
+                            else a.fcnt->overflow = 1;  // cannot happen below 3^5 frames; reported like any overflow
+                        }
+                        nn += (uint32_t)__popcll(m);
+                    }
                 }
-                if (lane == 0) s_n[L + 1] = nn;
             }
+            if (nn > (uint32_t)RTU_TAIL_CAP) nn = RTU_TAIL_CAP;
+            if (lane == 0 && L + 1 < levels) s_n[L + 1] = nn;
             n = nn;
         }
         // ---- combine bottom-up what waited for children (levels Ls .. last-1)
         for (int L = last - 1; L >= Ls; L--) {
             __threadfence();
             const uint32_t nL = s_n[L];
-            if (lane < nL && s_pend[L][lane]) combine_frame<TEX>(a, L, s_cur[L][lane]);
+            for (uint32_t i = lane; i < nL; i += 64u)
+                if (s_pend[L][i]) combine_frame<TEX>(a, L, s_cur[L][i]);
         }
         __threadfence();
     }
@@ -986,8 +996,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
         }
     }
-    // levels >= tail_from are evaluated by k_tail (fast variant only; the host passes tail_from >= 3, or 6 for none)
-    const int regular = (!stats && a.tail_from >= 3 && a.tail_from < levels) ? a.tail_from : levels;
+    // levels >= tail_from are evaluated by k_tail (fast variant only; the host passes tail_from >= 1, or 6 for none)
+    const int regular = (!stats && a.tail_from >= 1 && a.tail_from < levels) ? a.tail_from : levels;
     for (int L = 0; L < regular; L++) {
         const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
@@ -1004,7 +1014,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_consume<false, TEX>), gridF, block, 0, stream, a, L);
         }
     }
-    if (regular < levels) hipLaunchKernelGGL((k_tail<TEX>), dim3(1024), block, 0, stream, a, regular);
+    if (regular < levels) hipLaunchKernelGGL((k_tail<TEX>), dim3(8192), block, 0, stream, a, regular);
     for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
     return (int)hipGetLastError();
 }

@@ -606,7 +606,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 // After the stream has drained: did any recursion level run out of frame capacity?
 // Frames per level of the frame just finished -> where k_tail may take over in the next one.
 void learn_tail(RtuContext* ctx, const FrameCounters& h) {
-    const uint32_t kTailMax = 2048;  // frames of the cut level: one wavefront each
+    const uint32_t kTailMax = 256;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
+                                    // wavefront by wavefront are slower than their levels kernel by kernel
     uint32_t frames[RTU_MAX_LEVELS];
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         frames[L] = 0;
@@ -615,7 +616,7 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
     const int used = ctx->last_tail_from;  // levels > used were not materialised: their counts are unknown (zero)
     const int top = used < RTU_MAX_LEVELS ? used : RTU_MAX_LEVELS - 1;
     int hint = RTU_MAX_LEVELS;
-    for (int L = 3; L <= top; L++)
+    for (int L = 1; L <= top; L++)
         if (frames[L] <= kTailMax) { hint = L; break; }
     if (hint == RTU_MAX_LEVELS && used < RTU_MAX_LEVELS) hint = used + 1 < RTU_MAX_LEVELS ? used + 1 : RTU_MAX_LEVELS;
     ctx->tail_hint = hint;
@@ -1110,7 +1111,7 @@ int rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_u
 }
 
 int rtu_debug_tail_from(RtuContext* ctx, int level) {
-    if (!ctx || level < 3 || level > RTU_MAX_LEVELS) return RTU_ERR_ARG;
+    if (!ctx || level < 1 || level > RTU_MAX_LEVELS) return RTU_ERR_ARG;
     ctx->tail_hint = level;
     return RTU_OK;
 }

@@ -460,7 +460,7 @@ def test_frame_capacity_overflow_is_detected_and_repaired(pkg, orc, tmp_path):
 
 
 @pytest.mark.parametrize("tag", ["p4_240x135", "teapot2_240x135", "p13_200x150", "p7_200x150"])
-@pytest.mark.parametrize("level", [3, 4, 5])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
 def test_tail_kernel_any_cut_level(pkg, ctx, golden, tag, level):
     """Recursion levels >= `level` evaluated by k_tail (one wavefront per frame of that level, its
     whole Shade() subtree inside the wavefront) instead of the per-level kernels: the same image bit

@@ -38,6 +38,18 @@ lib.rtu_oracle_postprocess.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_i
                                        ctypes.c_void_p]
 
 
+lib.rtu_oracle_render_samples.restype = ctypes.c_int
+lib.rtu_oracle_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OracleStats), ctypes.c_int]
+lib.rtu_oracle_portable_sincos.restype = None
+lib.rtu_oracle_portable_sincos.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+for _n, _k in (("rtu_oracle_rand31", 2), ("rtu_oracle_sample_key", 2), ("rtu_oracle_child_key", 2)):
+    getattr(lib, _n).restype = ctypes.c_uint32
+    getattr(lib, _n).argtypes = [ctypes.c_uint32] * _k
+STREAM_KEYED, STREAM_SEQUENTIAL = 0, 1
+TRIG_PORTABLE, TRIG_LIBM = 0, 1
+
+
 class OracleError(RuntimeError):
     def __init__(self, code):
         self.code = code
@@ -54,6 +66,26 @@ def render(scene, width, height, threads=1, row0=0, nrows=None):
     if rc != 0:
         raise OracleError(rc)
     return out, st.as_dict()
+
+
+def render_samples(scene, width, height, spp, stream=STREAM_KEYED, trig=TRIG_PORTABLE, threads=1, row0=0, nrows=None):
+    """Recipe S (row f1): spp samples per pixel with soft shadows / glossy bounces / depth of field."""
+    if nrows is None:
+        nrows = height - row0
+    out = np.empty((nrows, width, 4), np.float32)
+    st = OracleStats()
+    rc = lib.rtu_oracle_render_samples(scene.desc_ptr, width, height, row0, nrows, spp, stream, trig, out.ctypes.data,
+                                       ctypes.byref(st), threads)
+    if rc != 0:
+        raise OracleError(rc)
+    return out, st.as_dict()
+
+
+def portable_sincos(t):
+    t = np.ascontiguousarray(t, np.float32)
+    s, c = np.empty_like(t), np.empty_like(t)
+    lib.rtu_oracle_portable_sincos(t.ctypes.data, t.size, s.ctypes.data, c.ctypes.data)
+    return s, c
 
 
 def camera_frame(camera, width, height):

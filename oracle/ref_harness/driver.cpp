@@ -359,6 +359,76 @@ static void RenderRows(int y0, int y1, Point3 org, float* z, float* rgb, std::at
     (void)H;
 }
 
+// ---- recipe S ("next" row f1) -----------------------------------------------
+// The sample loop of Render() (RenderFunctions.cpp:73-152) with spp samples instead of the
+// hard-coded 1024 and direct lighting only, every sample traced and shaded in turn. Every rand()
+// call of the reference (lightFunctions.cpp:47-48, RenderFunctions.cpp:291-293 via
+// mtlFunctions.cpp:164,226,276) and of this loop is redirected at link time (-Wl,--wrap=rand) to a
+// counter-based stream: the n-th call while sample `index` of pixel `p` is evaluated returns
+// rand31(sample_key(p, index), n) — the "sequential" stream of oracle/rtu_oracle.cpp, so that
+// restatement can be compared with this build bit for bit.
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+static thread_local uint32_t t_key = 0, t_counter = 0;
+extern "C" int __wrap_rand(void) {
+    return (int)(mix32(t_key ^ mix32((t_counter++) * 0x9e3779b9U + 0x85ebca6bU)) >> 1);
+}
+
+static void RenderRowsSampled(int y0, int y1, int spp, float* z, float* rgb, std::atomic<long long>* hits) {
+    const int W = camera.imgWidth;
+    long long nh = 0;
+    float pixelIncrement = 1.0 / spp;
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < W; x++) {
+            Color pixelValuesSum = Color(0.0, 0.0, 0.0);
+            float zSum = 0.0;
+            int numOfHits = 0;
+            for (int index = 0; index < spp; index++) {
+                t_key = mix32(mix32((uint32_t)(x + W * y) + 0x68bc21ebU) ^ ((uint32_t)index * 0x9e3779b9U + 1U));
+                t_counter = 0;
+                Point3 imgOrigin = CalculateImageOrigin(camera.focaldist);
+                float currentOffset = index * pixelIncrement;
+                float offsetX = Halton(index, 4);
+                float offsetY = Halton(index, 5);
+                float sampleX = static_cast<float>(rand()) / static_cast<float>(RAND_MAX);
+                float sampleTheta = static_cast<float>(rand()) / (static_cast<float>(RAND_MAX / (2 * M_PI)));
+                float camOffsetX = sqrt(sampleX * camera.dof * camera.dof) * cos(sampleTheta);
+                float camOffsetY = sqrt(sampleX * camera.dof * camera.dof) * sin(sampleTheta);
+                Point3 sampledPosition = camera.pos + camera.up * camOffsetY +
+                                         camera.dir.GetNormalized().Cross(camera.up.GetNormalized()).GetNormalized() * camOffsetX;
+                Point3 currentPoint = CalculateCurrentPoint(x, y, currentOffset + offsetX, currentOffset + offsetY, imgOrigin);
+                Ray ray = Ray(sampledPosition, (currentPoint - sampledPosition).GetNormalized());
+                HitInfo h;
+                Color c;
+                if (Trace(ray, &rootNode, h)) {
+                    nh++;
+                    zSum += h.z;
+                    numOfHits++;
+                    const Material* mtl = h.node->GetMaterial();
+                    c = mtl ? mtl->Shade(ray, h, lights, 5) : Color(1, 1, 1);
+                } else {
+                    c = background.Sample(Point3((float)x / camera.imgWidth, (float)y / camera.imgHeight, 0));
+                }
+                pixelValuesSum += c;
+            }
+            pixelValuesSum /= (float)spp;
+            int i = x + W * y;
+            z[i] = numOfHits ? zSum / (float)numOfHits : BIGFLOAT;
+            rgb[3 * i + 0] = pixelValuesSum.r; rgb[3 * i + 1] = pixelValuesSum.g; rgb[3 * i + 2] = pixelValuesSum.b;
+            Color g = pixelValuesSum;
+            g.r = pow(g.r, 1 / 2.2);
+            g.g = pow(g.g, 1 / 2.2);
+            g.b = pow(g.b, 1 / 2.2);
+            renderImage.GetPixels()[i] = Color24(g);
+            renderImage.GetZBuffer()[i] = z[i];
+            renderImage.IncrementNumRenderPixel(1);
+        }
+    }
+    hits->fetch_add(nh);
+}
+
 static bool WriteFile(const std::string& path, const void* p, size_t n) {
     FILE* fp = fopen(path.c_str(), "wb");
     if (!fp) return false;
@@ -369,7 +439,7 @@ static bool WriteFile(const std::string& path, const void* p, size_t n) {
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s scene.xml width height outdir [threads] [--scene-only]\n", argv[0]);
+        fprintf(stderr, "usage: %s scene.xml width height outdir [threads] [--scene-only | --spp N]\n", argv[0]);
         return 1;
     }
     const char* xml = argv[1];
@@ -377,6 +447,7 @@ int main(int argc, char** argv) {
     std::string out = argv[4];
     int threads = argc > 5 ? atoi(argv[5]) : 1;
     bool sceneOnly = argc > 6 && strcmp(argv[6], "--scene-only") == 0;
+    int spp = (argc > 7 && strcmp(argv[6], "--spp") == 0) ? atoi(argv[7]) : 0;  // 0: recipe W
     if (threads < 1) threads = 1;
 
     if (!LoadScene(xml)) return 3;
@@ -401,7 +472,8 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) {
         int y0 = (int)((long long)H * t / threads), y1 = (int)((long long)H * (t + 1) / threads);
-        th.emplace_back(RenderRows, y0, y1, org, z.data(), rgb.data(), &hits);
+        if (spp > 0) th.emplace_back(RenderRowsSampled, y0, y1, spp, z.data(), rgb.data(), &hits);
+        else th.emplace_back(RenderRows, y0, y1, org, z.data(), rgb.data(), &hits);
     }
     for (auto& t : th) t.join();
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -416,11 +488,11 @@ int main(int argc, char** argv) {
 
     FILE* fp = fopen((out + "/stats.json").c_str(), "w");
     fprintf(fp,
-            "{\"width\": %d, \"height\": %d, \"threads\": %d, \"seconds\": %.6f, \"primary\": %lld, "
+            "{\"width\": %d, \"height\": %d, \"spp\": %d, \"threads\": %d, \"seconds\": %.6f, \"primary\": %lld, "
             "\"primary_hits\": %lld, \"secondary\": %lld, \"shadow\": %lld}\n",
-            W, H, threads, sec, (long long)W * H, hits.load(), g_secondary.load(), g_shadow.load());
+            W, H, spp, threads, sec, (long long)W * H * (spp > 0 ? spp : 1), hits.load(), g_secondary.load(), g_shadow.load());
     fclose(fp);
-    printf("recipe W %dx%d: %.3f s, hits %lld, secondary %lld, shadow %lld\n", W, H, sec, hits.load(),
+    printf("recipe %s %dx%d: %.3f s, hits %lld, secondary %lld, shadow %lld\n", spp > 0 ? "S" : "W", W, H, sec, hits.load(),
            g_secondary.load(), g_shadow.load());
     return 0;
 }

@@ -18,9 +18,12 @@
 // -march=native / -Ofast).
 //
 // Scope: deterministic "recipe W" (SURVEY.md §8c): one ray through every pixel
-// centre, Trace + Shade(...,5). Stochastic features (soft shadows, glossy
-// bounces, depth of field) make the reference non-deterministic; scenes that use
-// them are rejected with RTU_ORACLE_ERR_STOCHASTIC.
+// centre, Trace + Shade(...,5); scenes with stochastic features (soft shadows, glossy
+// bounces, depth of field) are rejected there with RTU_ORACLE_ERR_STOCHASTIC.
+// "Recipe S" (row f1, rtu_oracle_render_samples): the sample loop of Render() with those
+// features, rand() replaced by counter-based sample streams (see "Sample streams" below).
+// Its pin: with the sequential stream and libm's sinf/cosf it equals, bit for bit, the
+// reference built with rand() wrapped to the same stream (oracle/ref_harness --spp).
 #include "rtu_oracle.h"
 
 #include <atomic>
@@ -91,7 +94,66 @@ inline float smin(float a, float b) { return (b < a) ? b : a; }
 struct Ctx {
     const RtuSceneDesc* s;
     RtuOracleStats st;  // per-thread counters
+    // sample streams ("next" row f1): where the integers that replace rand() come from
+    bool sequential;     // true: the n-th rand() call of a pixel sample (pins the restatement against the reference)
+    bool libm_trig;      // true: cosf/sinf of libm as the reference calls them; false: the portable sincos the device uses
+    uint32_t seq_key, seq_counter;
 };
+
+// ---------------------------------------------------------------------------
+// Sample streams. The reference draws from rand() (shared by its threads, seeded with time(NULL):
+// RenderFunctions.cpp:60) — nothing to reproduce bit for bit. Restated: every rand() call becomes
+// draw(), an integer in [0, RAND_MAX] from a counter-based hash; the float expressions around it are
+// the reference's. Two ways to index the stream:
+//   sequential  rand31(sample_key(pixel, sample), n) for the n-th call while that pixel sample is
+//               evaluated — the reference's own call order, so a reference build whose rand() is
+//               wrapped (oracle/ref_harness, -Wl,--wrap=rand) must give the same image bit for bit;
+//   keyed       rand31(key of the Shade() call, purpose) — independent of evaluation order, which is
+//               what a level-synchronous device evaluation needs. Keys: the primary Shade() of a
+//               sample has sample_key; a child Shade() has child_key(parent, slot).
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+inline uint32_t rand31(uint32_t key, uint32_t idx) { return mix32(key ^ mix32(idx * 0x9e3779b9U + 0x85ebca6bU)) >> 1; }
+inline uint32_t sample_key(uint32_t pixel, uint32_t sample) { return mix32(mix32(pixel + 0x68bc21ebU) ^ (sample * 0x9e3779b9U + 1U)); }
+inline uint32_t child_key(uint32_t key, uint32_t slot) { return mix32(key + (slot + 1U) * 0x632be5abU); }
+enum { DRAW_DOF = 0, DRAW_LIGHT = 16, DRAW_REFR1 = 0x10000, DRAW_REFR2 = 0x20000, DRAW_REFL = 0x30000 };
+enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };  // refracted (or TIR) ray, Fresnel ray, reflection ray
+inline float draw(Ctx& cx, uint32_t key, uint32_t idx) {  // static_cast<float>(rand())
+    return (float)(cx.sequential ? rand31(cx.seq_key, cx.seq_counter++) : rand31(key, idx));
+}
+const float RAND_MAX_F = (float)2147483647;                          // static_cast<float>(RAND_MAX)
+const float THETA_DIV = (float)(2147483647 / (2 * M_PI));            // static_cast<float>(RAND_MAX/(2 * M_PI))
+
+// sin and cos of a float angle in [0, 2*pi], evaluated in binary64 with IEEE operations only (the same
+// sequence on the device), rounded to float: within 1 ulp of libm's sinf/cosf (tests/test_oracle.py).
+inline void portable_sincos(float t, float* sn, float* cs) {
+    const double x = (double)t;
+    const double kd = floor(x * 6.36619772367581382433e-01 + 0.5);
+    const int k = (int)kd;
+    const double y = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double y2 = y * y;
+    const double ps = -1.66666666666666324348e-01 + y2 * (8.33333333332248946124e-03 + y2 * (-1.98412698298579493134e-04 +
+                      y2 * (2.75573137070700676789e-06 + y2 * (-2.50507602534068634195e-08 + y2 * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + y2 * (-1.38888888888741095749e-03 + y2 * (2.48015872894767294178e-05 +
+                      y2 * (-2.75573143513906633035e-07 + y2 * (2.08757232129817482790e-09 + y2 * -1.13596475577881948265e-11))));
+    const double s = y + (y * y2) * ps;
+    const double c = 1.0 - (0.5 * y2 - (y2 * y2) * pc);
+    double so, co;
+    switch (k & 3) {
+        case 0: so = s; co = c; break;
+        case 1: so = c; co = -s; break;
+        case 2: so = -s; co = -c; break;
+        default: so = -c; co = s; break;
+    }
+    *sn = (float)so;
+    *cs = (float)co;
+}
+inline void sincos_of(const Ctx& cx, float t, float* sn, float* cs) {
+    if (cx.libm_trig) { *sn = sinf(t); *cs = cosf(t); }  // sin(float) / cos(float): the float overloads
+    else portable_sincos(t, sn, cs);
+}
 
 // ---------------------------------------------------------------------------
 // cyMatrix.h Matrix3 * Point3 (cyMatrix.h:543-547), column-major data[9].
@@ -397,8 +459,9 @@ float shadow(Ctx& cx, const Ray& ray, float t_max) {
 }
 
 // Light::Illuminate: AmbientLight (lights.h:32), DirectLight (lights.h:48),
-// PointLight size==0 (lightFunctions.cpp:39-84).
-C3 illuminate(Ctx& cx, const RtuLight& l, V3 p) {
+// PointLight (lightFunctions.cpp:39-84; size > 0: one shadow ray towards a random point of the
+// light's disk, :43-65).
+C3 illuminate(Ctx& cx, const RtuLight& l, V3 p, uint32_t key, uint32_t light_index) {
     C3 intensity = ldc(l.intensity);
     if (l.type == RTU_LIGHT_AMBIENT) return intensity;
     if (l.type == RTU_LIGHT_DIRECT) {
@@ -407,8 +470,23 @@ C3 illuminate(Ctx& cx, const RtuLight& l, V3 p) {
     }
     V3 position = ld3(l.vec);
     float shadowIntensity = 0.0f;
-    Ray sr; sr.p = p; sr.dir = normalized(position - p);       // :76
-    shadowIntensity += shadow(cx, sr, length(position - p));   // :78
+    if (l.size > 0) {
+        float sampleR = draw(cx, key, DRAW_LIGHT + 2 * light_index) / (RAND_MAX_F / l.size);   // :47
+        float sampleTheta = draw(cx, key, DRAW_LIGHT + 2 * light_index + 1) / THETA_DIV;        // :48
+        float sn, cs;
+        sincos_of(cx, sampleTheta, &sn, &cs);
+        float offsetX = sampleR * cs;  // :49
+        float offsetY = sampleR * sn;  // :50
+        V3 samplePlaneNormal = normalized(position - p);                       // :52
+        V3 v1 = normalized(cross(samplePlaneNormal, mk(0, 0, 1)));             // :55
+        V3 v2 = normalized(cross(v1, samplePlaneNormal));                      // :56
+        V3 currentSamplePos = (position + v1 * offsetX) + v2 * offsetY;        // :58
+        Ray sr; sr.p = p; sr.dir = normalized(currentSamplePos - p);           // :60
+        shadowIntensity += shadow(cx, sr, length(p - currentSamplePos));       // :62
+    } else {
+        Ray sr; sr.p = p; sr.dir = normalized(position - p);       // :76
+        shadowIntensity += shadow(cx, sr, length(position - p));   // :78
+    }
     float result = shadowIntensity;
     return (intensity * result) * (1 / length_sq(position - p));  // :83
 }
@@ -493,18 +571,36 @@ inline C3 env_sample(const RtuSceneDesc& s, V3 dir) {
     return env_color_sample(s, s.environment, s.environment_map, uvw);
 }
 
-C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount);
+C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key);
 
-inline C3 shade_node(Ctx& cx, const Hit& h, const Ray& ray, int bounce) {
+inline C3 shade_node(Ctx& cx, const Hit& h, const Ray& ray, int bounce, uint32_t key) {
     int mid = cx.s->nodes[h.node].material_id;
     if (mid < 0) return mkc(1, 1, 1);  // null material => white (reference would crash)
-    return shade(cx, mid, ray, h, bounce);
+    return shade(cx, mid, ray, h, bounce, key);
 }
 
-// sampledNormal of mtlFunctions.cpp:162-165 with SampleSphere(...,0) == (0,0,0)
-inline V3 sampled_normal(const Hit& h) {
+// SampleSphere (RenderFunctions.cpp:282-301): a point of the cube [-radius, radius]^3, drawn again
+// while it lies outside the sphere. radius == 0 gives (0,0,0) (x / inf == 0) but still draws three
+// numbers, which matters to the sequential stream only. At most 64 attempts (p < 1e-20).
+inline V3 sample_sphere(Ctx& cx, float radius, uint32_t key, uint32_t base) {
+    V3 offset = mk(0, 0, 0);
+    if (!(radius > 0)) {
+        if (cx.sequential) cx.seq_counter += 3;
+        return offset;
+    }
+    for (uint32_t attempt = 0; attempt < 64; attempt++) {
+        float rand1 = -radius + draw(cx, key, base + 3 * attempt) / (RAND_MAX_F / (radius * 2));      // :291
+        float rand2 = -radius + draw(cx, key, base + 3 * attempt + 1) / (RAND_MAX_F / (radius * 2));  // :292
+        float rand3 = -radius + draw(cx, key, base + 3 * attempt + 2) / (RAND_MAX_F / (radius * 2));  // :293
+        offset = mk(rand1, rand2, rand3);
+        if (!(length(offset) > radius)) break;  // :297
+    }
+    return offset;
+}
+// sampledNormal of mtlFunctions.cpp:162-165, 225-227, 275-277
+inline V3 sampled_normal(Ctx& cx, const Hit& h, float glossiness, uint32_t key, uint32_t base) {
     V3 sampleOrigin = h.p + h.N;
-    V3 sampledOffset = mk(0, 0, 0);
+    V3 sampledOffset = sample_sphere(cx, glossiness, key, base);
     return normalized((sampleOrigin + sampledOffset) - h.p);
 }
 inline V3 reflect_dir(V3 dir, V3 sn) {  // :207, :239, :280
@@ -513,7 +609,7 @@ inline V3 reflect_dir(V3 dir, V3 sn) {  // :207, :239, :280
 }
 
 // MtlBlinn::Shade (mtlFunctions.cpp:120-298)
-C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount) {
+C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key) {
     const RtuMaterial& m = cx.s->materials[mtl_id];
     const RtuSceneDesc& s = *cx.s;
     C3 result = mkc(0, 0, 0);
@@ -522,7 +618,7 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
         for (uint32_t i = 0; i < s.n_lights; i++) {
             const RtuLight& l = s.lights[i];
             if (l.type == RTU_LIGHT_AMBIENT) {
-                result += diffuse * illuminate(cx, l, hInfo.p);  // :132
+                result += diffuse * illuminate(cx, l, hInfo.p, key, i);  // :132
             } else {
                 V3 viewDirection = normalized(ld3(s.camera.pos) - hInfo.p);          // :137
                 V3 lightDirection = normalized(-light_direction(l, hInfo.p));       // :138
@@ -531,14 +627,14 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
                 float NDotH = dot(hInfo.N, halfVector);
                 if (NDotL < 0.0) NDotL = 0.0;
                 if (NDotH < 0.0) NDotH = 0.0;
-                result += (illuminate(cx, l, hInfo.p) * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
+                result += (illuminate(cx, l, hInfo.p, key, i) * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
             }
         }
     }
     if (bounceCount > 0) {
         C3 refraction = mtl_color(s, mtl_id, RTU_MAP_REFRACTION, m.refraction, hInfo.uvw);
         if (not_black(refraction)) {  // :160
-            V3 sampledNormal = sampled_normal(hInfo);
+            V3 sampledNormal = sampled_normal(cx, hInfo, m.refraction_glossiness, key, DRAW_REFR1);  // :162-165
             float cosTheta1 = dot(sampledNormal, -ray.dir);
             float sinTheta1 = (float)sqrt(1 - (double)cosTheta1 * (double)cosTheta1);  // :169, pow(x,2) exact
             if (sinTheta1 > 1) sinTheta1 = 1.0;
@@ -562,11 +658,11 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
                 C3 absorptionV = mkc(expf((-rh.z) * absorption.r), expf((-rh.z) * absorption.g), expf((-rh.z) * absorption.b));  // :213, z==BIGFLOAT
                 cx.st.secondary_rays++;
                 if (trace(cx, reflected, 0, rh)) {
-                    C3 TIRResult = absorptionV * shade_node(cx, rh, reflected, bounceCount - 1);
+                    C3 TIRResult = absorptionV * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_MAIN));
                     result += TIRResult;
                 }
             } else {
-                V3 sn2 = sampled_normal(hInfo);  // :225-227 (second sample, same value)
+                V3 sn2 = sampled_normal(cx, hInfo, m.refraction_glossiness, key, DRAW_REFR2);  // :225-227: a second sample, it shadows the first
                 Ray refracted; refracted.p = hInfo.p;
                 refracted.dir = normalized((-sn2) * cosTheta2 + SVector * sinTheta2);  // :229
                 Hit fh = new_hit();
@@ -579,9 +675,9 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
                     Hit rh = new_hit();
                     C3 frenselResult;
                     cx.st.secondary_rays++;
-                    if (trace(cx, reflected, 0, rh)) frenselResult = refraction * shade_node(cx, rh, reflected, bounceCount - 1);  // :247
+                    if (trace(cx, reflected, 0, rh)) frenselResult = refraction * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_A));  // :247
                     else frenselResult = env_sample(s, reflected.dir);                                                             // :250
-                    C3 refractionResult = shade_node(cx, fh, refracted, bounceCount - 1);  // :254
+                    C3 refractionResult = shade_node(cx, fh, refracted, bounceCount - 1, child_key(key, SLOT_MAIN));  // :254
                     C3 absorptionV = mkc(1, 1, 1);
                     if (!fh.front)
                         absorptionV = mkc(expf((-fh.z) * absorption.r), expf((-fh.z) * absorption.g), expf((-fh.z) * absorption.b));  // :259
@@ -594,11 +690,11 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount)
         }
         C3 reflection = mtl_color(s, mtl_id, RTU_MAP_REFLECTION, m.reflection, hInfo.uvw);
         if (not_black(reflection)) {  // :273
-            V3 sampledNormal = sampled_normal(hInfo);
+            V3 sampledNormal = sampled_normal(cx, hInfo, m.reflection_glossiness, key, DRAW_REFL);  // :275-277
             Ray reflected; reflected.p = hInfo.p; reflected.dir = reflect_dir(ray.dir, sampledNormal);
             Hit rh = new_hit();
             cx.st.secondary_rays++;
-            if (trace(cx, reflected, 0, rh)) result += reflection * shade_node(cx, rh, reflected, bounceCount - 1);  // :286
+            if (trace(cx, reflected, 0, rh)) result += reflection * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_C));  // :286
             else result += env_sample(s, reflected.dir) * ldc(m.reflection);  // :289: reflection.GetColor(), not the sampled colour
         }
     }
@@ -633,32 +729,95 @@ void add_stats(RtuOracleStats& a, const RtuOracleStats& b) {
     a.tri_tests += b.tri_tests; a.tri_accepts += b.tri_accepts;
 }
 
+// Halton (scene.h:130-139)
+inline float halton(int index, int base) {
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) {
+        r += f * (i % base);
+        f /= (float)base;
+    }
+    return r;
+}
+
+struct Sampling {
+    int spp;          // 0: recipe W (one ray through the pixel centre); S >= 1: recipe S, the sample loop of Render()
+    bool sequential, libm_trig;
+};
+
 void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::atomic<int>* next_row, int y_begin,
-                 int y_end, int chunk, float* rgbz, RtuOracleStats* out) {
+                 int y_end, int chunk, float* rgbz, RtuOracleStats* out, Sampling sm) {
     Ctx cx;
     cx.s = s;
+    cx.sequential = sm.sequential;
+    cx.libm_trig = sm.libm_trig;
+    cx.seq_key = cx.seq_counter = 0;
     memset(&cx.st, 0, sizeof cx.st);
+    const V3 up = ld3(s->camera.up);
+    const V3 right = normalized(cross(normalized(ld3(s->camera.dir)), normalized(up)));
     for (;;) {
         int y0 = next_row->fetch_add(chunk);
         if (y0 >= y_end) break;
         int y1 = y0 + chunk < y_end ? y0 + chunk : y_end;
         for (int y = y0; y < y1; y++) {
             for (int x = 0; x < W; x++) {
-                // recipe W: CalculateCurrentPoint(x,y,0.5f,0.5f,org), RenderFunctions.cpp:258-268
-                V3 cp = (cf.origin + cf.u * ((float)x + 0.5f)) + cf.v * ((float)y + 0.5f);
-                Ray ray; ray.p = cf.pos; ray.dir = normalized(cp - cf.pos);  // :97
-                Hit h = new_hit();
-                cx.st.primary_rays++;
-                bool hit = trace(cx, ray, 0, h);  // :103
-                C3 c;
-                if (hit) {
-                    cx.st.primary_hits++;
-                    c = shade_node(cx, h, ray, RTU_MAX_BOUNCE);  // :134-135
-                } else {
-                    c = background_sample(*s, x, y);  // RenderFunctions.cpp:145
-                }
                 float* o = rgbz + 4 * ((size_t)(y - y_begin) * W + x);
-                o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = h.z;
+                if (sm.spp == 0) {
+                    // recipe W: CalculateCurrentPoint(x,y,0.5f,0.5f,org), RenderFunctions.cpp:258-268
+                    V3 cp = (cf.origin + cf.u * ((float)x + 0.5f)) + cf.v * ((float)y + 0.5f);
+                    Ray ray; ray.p = cf.pos; ray.dir = normalized(cp - cf.pos);  // :97
+                    Hit h = new_hit();
+                    cx.st.primary_rays++;
+                    bool hit = trace(cx, ray, 0, h);  // :103
+                    C3 c;
+                    if (hit) {
+                        cx.st.primary_hits++;
+                        c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, 0);  // :134-135
+                    } else {
+                        c = background_sample(*s, x, y);  // RenderFunctions.cpp:145
+                    }
+                    o[0] = c.r; o[1] = c.g; o[2] = c.b; o[3] = h.z;
+                    continue;
+                }
+                // recipe S: the sample loop of Render() (RenderFunctions.cpp:73-151) with spp in place of
+                // maxSampleSize, direct lighting only, every sample traced and shaded in turn.
+                const float pixelIncrement = (float)(1.0 / sm.spp);  // :68
+                C3 pixelValuesSum = mkc(0, 0, 0);
+                float zSum = 0.0f;
+                int numOfHits = 0;
+                for (int index = 0; index < sm.spp; index++) {
+                    const uint32_t key = sample_key((uint32_t)(x + W * y), (uint32_t)index);
+                    cx.seq_key = key;
+                    cx.seq_counter = 0;
+                    float currentOffset = index * pixelIncrement;  // :80
+                    float offsetX = halton(index, 4);              // :84
+                    float offsetY = halton(index, 5);              // :85
+                    float sampleX = draw(cx, key, DRAW_DOF) / RAND_MAX_F;          // :88
+                    float sampleTheta = draw(cx, key, DRAW_DOF + 1) / THETA_DIV;   // :89
+                    float sn, cs;
+                    sincos_of(cx, sampleTheta, &sn, &cs);
+                    float rad = sqrtf((sampleX * s->camera.dof) * s->camera.dof);
+                    float camOffsetX = rad * cs;  // :90
+                    float camOffsetY = rad * sn;  // :91
+                    V3 sampledPosition = (cf.pos + up * camOffsetY) + right * camOffsetX;  // :93
+                    V3 cp = (cf.origin + cf.u * ((float)x + (currentOffset + offsetX))) + cf.v * ((float)y + (currentOffset + offsetY));  // :96
+                    Ray ray; ray.p = sampledPosition; ray.dir = normalized(cp - sampledPosition);  // :97
+                    Hit h = new_hit();
+                    cx.st.primary_rays++;
+                    C3 c;
+                    if (trace(cx, ray, 0, h)) {  // :103
+                        cx.st.primary_hits++;
+                        zSum += h.z;  // :109
+                        numOfHits++;
+                        c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, key);  // :135
+                    } else {
+                        c = background_sample(*s, x, y);  // :145
+                    }
+                    pixelValuesSum += c;  // :148
+                }
+                // :152 (Color /= float divides) and the z of the commented-out :115
+                o[0] = pixelValuesSum.r / (float)sm.spp; o[1] = pixelValuesSum.g / (float)sm.spp; o[2] = pixelValuesSum.b / (float)sm.spp;
+                o[3] = numOfHits ? zSum / (float)numOfHits : RTU_BIGFLOAT;
             }
         }
     }
@@ -666,15 +825,15 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
     *out = cx.st;
 }
 
-int check_scene(const RtuSceneDesc* s) {
+int check_scene(const RtuSceneDesc* s, bool stochastic_ok) {
     if (!s || !s->nodes || s->n_nodes == 0) return RTU_ORACLE_ERR_ARG;
-    if (s->camera.dof != 0) return RTU_ORACLE_ERR_STOCHASTIC;
+    if (s->camera.dof != 0 && !stochastic_ok) return RTU_ORACLE_ERR_STOCHASTIC;
     for (uint32_t i = 0; i < s->n_textures; i++)
         if (s->textures[i].type == RTU_TEX_FILE && s->textures[i].width * s->textures[i].height > 0 && !s->textures[i].rgb) return RTU_ORACLE_ERR_ARG;
     for (uint32_t i = 0; i < s->n_lights; i++)
-        if (s->lights[i].type == RTU_LIGHT_POINT && s->lights[i].size > 0) return RTU_ORACLE_ERR_STOCHASTIC;
+        if (s->lights[i].type == RTU_LIGHT_POINT && s->lights[i].size > 0 && !stochastic_ok) return RTU_ORACLE_ERR_STOCHASTIC;
     for (uint32_t i = 0; i < s->n_materials; i++)
-        if (s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0) return RTU_ORACLE_ERR_STOCHASTIC;
+        if ((s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0) && !stochastic_ok) return RTU_ORACLE_ERR_STOCHASTIC;
     for (uint32_t i = 0; i < s->n_nodes; i++) {
         const RtuNode& n = s->nodes[i];
         if (n.obj_type == RTU_OBJ_TRIMESH && (n.mesh_id < 0 || (uint32_t)n.mesh_id >= s->n_meshes)) return RTU_ORACLE_ERR_ARG;
@@ -687,22 +846,22 @@ int check_scene(const RtuSceneDesc* s) {
 
 extern "C" {
 
-int rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, float* rgbz_out,
-                           RtuOracleStats* stats, int threads) {
-    int err = check_scene(scene);
+static int render_impl(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, float* rgbz_out,
+                       RtuOracleStats* stats, int threads, Sampling sm) {
+    int err = check_scene(scene, sm.spp >= 1);
     if (err) return err;
-    if (width <= 0 || height <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > height || !rgbz_out) return RTU_ORACLE_ERR_ARG;
+    if (width <= 0 || height <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > height || !rgbz_out || sm.spp < 0) return RTU_ORACLE_ERR_ARG;
     if (threads < 1) threads = 1;
     CamFrame cf = camera_frame(scene->camera, width, height);
     std::atomic<int> next(row0);
     std::vector<RtuOracleStats> st(threads);
     int chunk = 4;
     if (threads == 1) {
-        render_rows(scene, cf, width, height, &next, row0, row0 + nrows, nrows > 0 ? nrows : 1, rgbz_out, &st[0]);
+        render_rows(scene, cf, width, height, &next, row0, row0 + nrows, nrows > 0 ? nrows : 1, rgbz_out, &st[0], sm);
     } else {
         std::vector<std::thread> th;
         for (int t = 0; t < threads; t++)
-            th.emplace_back(render_rows, scene, cf, width, height, &next, row0, row0 + nrows, chunk, rgbz_out, &st[t]);
+            th.emplace_back(render_rows, scene, cf, width, height, &next, row0, row0 + nrows, chunk, rgbz_out, &st[t], sm);
         for (auto& t : th) t.join();
     }
     if (stats) {
@@ -711,6 +870,31 @@ int rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int
     }
     return 0;
 }
+
+int rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, float* rgbz_out,
+                           RtuOracleStats* stats, int threads) {
+    Sampling sm = {0, false, false};
+    return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
+}
+
+int rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp, int stream,
+                              int trig, float* rgbz_out, RtuOracleStats* stats, int threads) {
+    if (spp < 1 || (stream != RTU_ORACLE_STREAM_KEYED && stream != RTU_ORACLE_STREAM_SEQUENTIAL) ||
+        (trig != RTU_ORACLE_TRIG_PORTABLE && trig != RTU_ORACLE_TRIG_LIBM))
+        return RTU_ORACLE_ERR_ARG;
+    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM};
+    return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
+}
+
+// sin, cos of the portable evaluation, for the test that bounds it against libm.
+void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* cos_out) {
+    for (int i = 0; i < n; i++) portable_sincos(t[i], sin_out + i, cos_out + i);
+}
+
+// The integers of the sample streams, for the tests that pin the device's generator.
+uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx) { return rand31(key, idx); }
+uint32_t rtu_oracle_sample_key(uint32_t pixel, uint32_t sample) { return sample_key(pixel, sample); }
+uint32_t rtu_oracle_child_key(uint32_t key, uint32_t slot) { return child_key(key, slot); }
 
 int rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* rgbz_out, RtuOracleStats* stats, int threads) {
     return rtu_oracle_render_rows(scene, width, height, 0, height, rgbz_out, stats, threads);

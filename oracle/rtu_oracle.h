@@ -34,6 +34,21 @@ int  rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, in
                             float* rgbz_out, RtuOracleStats* stats, int threads);
 int  rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* rgbz_out,
                        RtuOracleStats* stats, int threads);
+/* Recipe S (row f1): spp samples per pixel as in the sample loop of Render() (RenderFunctions.cpp:73-152:
+ * Halton pixel offsets, depth of field, soft shadows, glossy bounces), direct lighting only; rgb = mean
+ * of the samples, z = mean hInfo.z of the samples that hit. stream: where the integers that replace
+ * rand() come from (see rtu_oracle.cpp "Sample streams"); trig: sinf/cosf of libm (as the reference
+ * calls them) or the portable evaluation the device uses. */
+#define RTU_ORACLE_STREAM_KEYED      0
+#define RTU_ORACLE_STREAM_SEQUENTIAL 1
+#define RTU_ORACLE_TRIG_PORTABLE     0
+#define RTU_ORACLE_TRIG_LIBM         1
+int  rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp,
+                               int stream, int trig, float* rgbz_out, RtuOracleStats* stats, int threads);
+void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* cos_out);
+uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx);
+uint32_t rtu_oracle_sample_key(uint32_t pixel, uint32_t sample);
+uint32_t rtu_oracle_child_key(uint32_t key, uint32_t slot);
 /* pos, origin, u, v of the image plane (RenderFunctions.cpp:243-269). */
 int  rtu_oracle_camera_frame(const RtuCamera* cam, int width, int height, float out12[12]);
 /* gamma + Color24 + z-image; any output pointer may be NULL. */

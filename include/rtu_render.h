@@ -39,7 +39,7 @@ extern "C" {
 #define RTU_ERR_ARG         (-1)  /* NULL / out-of-range argument */
 #define RTU_ERR_HIP         (-2)  /* a HIP runtime call failed (see rtu_last_error) */
 #define RTU_ERR_UNSUPPORTED (-3)  /* scene exceeds a device-path limit */
-#define RTU_ERR_STOCHASTIC  (-4)  /* soft shadows / glossy bounces / depth of field */
+#define RTU_ERR_STOCHASTIC  (-4)  /* soft shadows / glossy bounces / depth of field in a frame with samples == 0 */
 #define RTU_ERR_NO_SCENE    (-5)  /* render before rtu_upload_scene */
 #define RTU_ERR_NO_DEVICE   (-6)  /* no such GPU */
 #define RTU_ERR_CAPACITY    (-7)  /* more Shade() frames than provisioned (see rtu_frame_status) */
@@ -58,11 +58,33 @@ typedef struct RtuFrameDesc {
     int32_t collect_stats;            /* 1: fill the ray / traversal counters (slower kernel variant) */
     int32_t coop_threshold;           /* tuning: a deferred-ray list shorter than this is traced by the
                                          cooperative (8 lanes per ray) kernels; 0 = default */
-    int32_t reserved;
+    int32_t samples;                  /* 0: recipe W, one ray through every pixel centre (scenes with stochastic
+                                         features are refused, RTU_ERR_STOCHASTIC). S >= 1: recipe S, the sample loop
+                                         of Render() (RenderFunctions.cpp:73-152) with S samples per pixel: Halton
+                                         pixel offsets, depth of field, soft shadows, glossy bounces, on the sample
+                                         streams described below; rgb = mean of the samples, z = mean hInfo.z of the
+                                         samples that hit */
     float   cam_pos[3];               /* camera.pos */
     float   origin[3];                /* CalculateImageOrigin(camera.focaldist) */
     float   u[3], v[3];               /* per-pixel steps of CalculateCurrentPoint */
+    float   lens_up[3];               /* camera.up (as given) and normalize(dir x up): the lens disk of */
+    float   lens_right[3];            /* RenderFunctions.cpp:93 */
+    float   dof;                      /* camera.dof */
 } RtuFrameDesc;
+
+/* Sample streams of recipe S. The reference draws from rand() (shared by its threads, seeded with the
+ * time: RenderFunctions.cpp:60), which nothing can reproduce. Here every rand() call becomes
+ *     rand31(key, purpose) = mix32(key ^ mix32(purpose * 0x9e3779b9 + 0x85ebca6b)) >> 1     in [0, RAND_MAX]
+ *     mix32(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16
+ * inside the reference's own float expressions. key belongs to one Shade() call: the primary hit of sample
+ * i of pixel p (p = x + width * y in the whole image, whatever the sharding) has
+ *     sample_key(p, i) = mix32(mix32(p + 0x68bc21eb) ^ (i * 0x9e3779b9 + 1)),
+ * the Shade() of the hit of its secondary ray `slot` (0 refracted or totally reflected, 1 Fresnel
+ * reflection, 2 mirror reflection) has child_key(key, slot) = mix32(key + (slot + 1) * 0x632be5ab).
+ * purpose: 0, 1 lens sample (sampleX, sampleTheta); 16 + 2 l, 17 + 2 l light l's disk sample (sampleR,
+ * sampleTheta); 0x10000 / 0x20000 / 0x30000 + 3 a + {0,1,2}: attempt a of SampleSphere for the first /
+ * second refraction normal and for the reflection normal. sin and cos of sampleTheta are evaluated in
+ * binary64 with IEEE operations only (oracle/rtu_oracle.cpp portable_sincos states the sequence). */
 
 /* Ray and traversal counters of one frame (all shards of one context). Same
  * fields as RtuOracleStats so CPU and GPU can be compared exactly. */

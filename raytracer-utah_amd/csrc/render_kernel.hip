@@ -113,14 +113,14 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
 template <bool TEX>
-__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw) {
+__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp) {
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
     uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
     if (front && s.n_lights > 0) info |= RTU_FI_SH;                      // mtlFunctions.cpp:125
     if (bounce > 0) {                                                   // :158
         if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
             info |= RTU_FI_MAIN;
-            Refr r = refraction_terms(dir, p, N, front, m.ior);
+            Refr r = refraction_terms(dir, p, N, front, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
             if (r.sinTheta2 > 1) info |= RTU_FI_TIR;                    // :205
         }
         if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw))) info |= RTU_FI_C;  // :273
@@ -133,11 +133,32 @@ __device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Ini
 }
 
 // Direction of secondary ray `slot` of a frame (mtlFunctions.cpp:207, :229, :239, :280).
-__device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 p, f3 N, float ior) {
-    if (slot == SLOT_C) return reflect_dir(dir, sampled_normal(p, N));
-    Refr t = refraction_terms(dir, p, N, (info & RTU_FI_FRONT) != 0, ior);
-    if (slot == SLOT_A || (info & RTU_FI_TIR)) return reflect_dir(dir, t.sn);
-    return norm3((-t.sn) * t.cosTheta2 + t.SVector * t.sinTheta2);
+__device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 p, f3 N, const RTU_CONST RtuMaterial& m, Smp smp) {
+    if (slot == SLOT_C) return reflect_dir(dir, sampled_normal(p, N, smp, smp.on ? m.reflection_glossiness : 0.0f, RTU_DRAW_REFL));
+    Refr t = refraction_terms(dir, p, N, (info & RTU_FI_FRONT) != 0, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
+    if (info & RTU_FI_TIR) return reflect_dir(dir, t.sn);    // :207, the first sample
+    if (slot == SLOT_A) return reflect_dir(dir, t.sn2);      // :239, the second sample shadows the first
+    return norm3((-t.sn2) * t.cosTheta2 + t.SVector * t.sinTheta2);  // :229
+}
+
+// The key of the sample streams of the Shade() call a frame stands for (recipe S): level 0 frames
+// carry their pixel in fb.w, deeper frames their key.
+__device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) {
+    Smp smp;
+    smp.on = a.sampling != 0;
+    smp.key = 0;
+    if (smp.on) {
+        const uint32_t w = __float_as_uint(fbw);
+        if (L == 0) {
+            const uint32_t W = (uint32_t)a.frame.width;
+            const uint32_t ly = w / W, x = w - ly * W;
+            const uint32_t y = ((ly / RTU_BAND_ROWS) * (uint32_t)a.frame.shard_count + (uint32_t)a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS;
+            smp.key = sample_key(x + W * y, a.sample_index);
+        } else {
+            smp.key = w;
+        }
+    }
+    return smp;
 }
 
 // ------------------------------------------------------------------------------------
@@ -200,9 +221,26 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     ray.dir = mk3(0, 0, 0);
     int mid = -1;
     deferred = false;
+    Smp smp;
+    smp.on = a.sampling != 0;
+    smp.key = 0;
     if (valid) {
-        // RenderFunctions.cpp:258-268 (pixel centre), :97
-        f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + 0.5f)) + ld3(a.frame.v) * ((float)y + 0.5f);
+        float ox = 0.5f, oy = 0.5f;  // recipe W: the pixel centre
+        if (smp.on) {
+            // recipe S: RenderFunctions.cpp:80-97 — Halton offsets, a point of the lens disk
+            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index);
+            ox = a.pix_off_x;
+            oy = a.pix_off_y;
+            const float sampleX = (float)rand31(smp.key, RTU_DRAW_LENS) / RTU_RAND_MAX_F;          // :88
+            const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LENS + 1u) / RTU_THETA_DIV;  // :89
+            float sn, cs;
+            portable_sincos(sampleTheta, sn, cs);
+            const float rad = sqrtf((sampleX * a.frame.dof) * a.frame.dof);
+            const float camOffsetX = rad * cs, camOffsetY = rad * sn;                               // :90-91
+            ray.p = (ray.p + ld3(a.frame.lens_up) * camOffsetY) + ld3(a.frame.lens_right) * camOffsetX;  // :93
+        }
+        // RenderFunctions.cpp:258-268, :97
+        f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + ox)) + ld3(a.frame.v) * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
         bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEX>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
@@ -221,7 +259,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     // the frame's info word first, then its three appends (frame array, the two slot lists) issued
     // back to back: one wait for the wavefront instead of three
     uint32_t info = 0;
-    if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw);
+    if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
     const LevelBuffers& lv = a.lv[0];
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
     const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
@@ -370,12 +408,27 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     const bool is_shadow = slot < a.nsl;
     const int sslot = (int)slot - (int)a.nsl;
     if (is_shadow) {
-        // ---- shadow ray (lightFunctions.cpp:27-37, 75-78; lights.h:48)
+        // ---- shadow ray (lightFunctions.cpp:27-37, 43-65, 75-78; lights.h:48)
         if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) return false;
-        const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[slot]];
+        const int li = a.shadow_light[slot];
+        const RTU_CONST RtuLight& l = as_const(s.lights)[li];
         f3 lvec = ld3(l.vec);
         if (l.type == RTU_LIGHT_DIRECT) {
             r.dir = -lvec;
+        } else if (a.sampling && l.size > 0) {
+            // soft shadow: one ray towards a random point of the light's disk
+            const Smp smp = frame_smp(a, L, lv.fb[f].w);
+            const float sampleR = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li) / (RTU_RAND_MAX_F / l.size);  // :47
+            const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li + 1u) / RTU_THETA_DIV;     // :48
+            float sn, cs;
+            portable_sincos(sampleTheta, sn, cs);
+            const float offsetX = sampleR * cs, offsetY = sampleR * sn;         // :49-50
+            const f3 samplePlaneNormal = norm3(lvec - p);                      // :52
+            const f3 v1 = norm3(cross3(samplePlaneNormal, mk3(0, 0, 1)));      // :55
+            const f3 v2 = norm3(cross3(v1, samplePlaneNormal));                // :56
+            const f3 currentSamplePos = (lvec + v1 * offsetX) + v2 * offsetY;  // :58
+            r.dir = norm3(currentSamplePos - p);                               // :60
+            tmax = len3(p - currentSamplePos);                                 // :62
         } else {
             r.dir = norm3(lvec - p);
             tmax = len3(lvec - p);
@@ -393,8 +446,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         }
         const float4 fb = lv.fb[f], fc = lv.fc[f];
         const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-        const float ior = as_const(s.materials)[info & RTU_FI_MTL_MASK].ior;
-        r.dir = secondary_dir(sslot, info, dir, p, N, ior);
+        r.dir = secondary_dir(sslot, info, dir, p, N, as_const(s.materials)[info & RTU_FI_MTL_MASK], frame_smp(a, L, fb.w));
         RTU_CNT(sec);
     }
     Hit h;
@@ -525,12 +577,13 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
 // known. st* >= 0 or RTU_CH_WHITE: that ray hit and ret* holds Shade() of the hit.
 template <bool TEX>
 __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMaterial& m, uint32_t info, f3 direct, f3 dir, f3 p,
-                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront, f3 uvw) {
+                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront, f3 uvw,
+                                       Smp smp) {
     const bool front = (info & RTU_FI_FRONT) != 0;
     const int mtl = (int)(info & RTU_FI_MTL_MASK);
     // environment.SampleEnvironment(direction of the ray that missed); a constant without an environment map
     auto env_at = [&](int slot) {
-        return (TEX && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m.ior)) : ld3(s.environment);
+        return (TEX && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m, smp)) : ld3(s.environment);
     };
     f3 result = direct;
     if (info & RTU_FI_MAIN) {
@@ -539,7 +592,7 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
         if (info & RTU_FI_TIR) {
             if (mainHit) result = result + absorb(RTU_BIGFLOAT, absorption) * retMain;  // :210-221 (z of a fresh HitInfo)
         } else if (mainHit) {
-            Refr r = refraction_terms(dir, p, N, front, m.ior);
+            Refr r = refraction_terms(dir, p, N, front, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
             float S = schlick(r);                                                        // :236-237
             f3 absorptionV = mk3(1, 1, 1);
             if (!bfront) absorptionV = absorb(bz, absorption);                           // :258-262
@@ -578,6 +631,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
     const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
+    const Smp smp = frame_smp(a, L, fb.w);
     f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
     if (TEX && active) {
         const float4 t = lv.fuv[f];
@@ -679,7 +733,10 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         else if (spawn[k] && cfl[k] < nx.cap_s) {
             const uint32_t idx = cfl[k] + cshard * nx.cap_s;
             // the child Shade(): ray direction, hit point and normal of the secondary ray
-            const f3 cdir = secondary_dir(k, info, dir, p, N, m.ior);
+            const f3 cdir = secondary_dir(k, info, dir, p, N, m, smp);
+            Smp csmp;
+            csmp.on = smp.on;
+            csmp.key = smp.on ? child_key(smp.key, (uint32_t)k) : 0u;
             const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
             f3 cuvw = mk3(0, 0, 0);
             if (TEX) {
@@ -687,9 +744,9 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
                 cuvw = mk3(t.x, t.y, t.z);
                 nx.fuv[idx] = t;
             }
-            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw);
+            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp);
             nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, 0.0f);
+            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(csmp.key));
             nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
             st[k] = (int)idx;
             wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
@@ -731,7 +788,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
     if (!pending) {
         const f3 one = mk3(1, 1, 1);
-        const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw);
+        const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw, smp);
         if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
         else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
     } else {
@@ -790,7 +847,8 @@ __device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32
         const float4 t = lv.fuv[f];
         uvw = mk3(t.x, t.y, t.z);
     }
-    const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw);
+    const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw,
+                               frame_smp(a, L, fb.w));
     if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
     else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
 }
@@ -1020,6 +1078,39 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
 }
 
 }  // namespace
+
+// ---- recipe S: the sums of RenderFunctions.cpp:109-110,148 in sample order, and :152 -----------
+namespace {
+__global__ void __launch_bounds__(256) k_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, int first) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pixels) return;
+    const float4 v = sample[i];
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t n = 0;
+    if (!first) { s = acc[i]; n = hits[i]; }
+    s.x += v.x; s.y += v.y; s.z += v.z;                // pixelValuesSum += currentResult
+    if (v.w != RTU_BIGFLOAT) { s.w += v.w; n++; }      // zSum += z; numOfHits++
+    acc[i] = s;
+    hits[i] = n;
+}
+__global__ void __launch_bounds__(256) k_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pixels) return;
+    const float4 s = acc[i];
+    const uint32_t n = hits[i];
+    const float S = (float)samples;
+    out[i] = make_float4(s.x / S, s.y / S, s.z / S, n ? s.w / (float)n : RTU_BIGFLOAT);
+}
+}  // namespace
+
+int rtu_launch_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream) {
+    hipLaunchKernelGGL(k_accumulate, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, sample, acc, hits, pixels, first ? 1 : 0);
+    return (int)hipGetLastError();
+}
+int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples, hipStream_t stream) {
+    hipLaunchKernelGGL(k_resolve, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, acc, hits, out, pixels, samples);
+    return (int)hipGetLastError();
+}
 
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream) {
     hipLaunchKernelGGL(k_selftest_fdiv, dim3(4096), dim3(256), 0, stream, n_pairs, seed, d_mismatches);

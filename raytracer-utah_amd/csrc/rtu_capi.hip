@@ -36,6 +36,11 @@ struct RtuContext {
     uint32_t  defer_cap_s = 0;
     bool     any_recursive_material = true;
     bool     textured = false;
+    bool     scene_stochastic = false;   // soft shadows / glossy bounces / depth of field: recipe S only
+    std::string stochastic_what;
+    float4*   acc = nullptr;             // recipe S accumulators: rgb sum + z sum, hit count
+    uint32_t* acc_hits = nullptr;
+    size_t    acc_pixels = 0;
     // k_tail: the recursion level from which the previous frame of this scene was almost empty (a hint —
     // any value renders the same image); last_tail_from: what the most recent frame was launched with
     int      tail_hint = RTU_MAX_LEVELS, last_tail_from = RTU_MAX_LEVELS;
@@ -404,7 +409,6 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
     if (s->n_materials && !s->materials) return fail(ctx, RTU_ERR_ARG, "materials is NULL");
     if (s->n_lights && !s->lights) return fail(ctx, RTU_ERR_ARG, "lights is NULL");
     if (s->n_meshes && !s->meshes) return fail(ctx, RTU_ERR_ARG, "meshes is NULL");
-    if (s->camera.dof != 0) return fail(ctx, RTU_ERR_STOCHASTIC, "depth of field is stochastic");
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const RtuTexture& t = s->textures[i];
         if (t.type != RTU_TEX_FILE && t.type != RTU_TEX_CHECKER) return fail(ctx, RTU_ERR_ARG, "texture %u: unknown type", i);
@@ -422,16 +426,12 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
     for (uint32_t i = 0; i < s->n_lights; i++) {
         const RtuLight& l = s->lights[i];
         if (l.type < RTU_LIGHT_AMBIENT || l.type > RTU_LIGHT_POINT) return fail(ctx, RTU_ERR_ARG, "light %u: bad type", i);
-        if (l.type == RTU_LIGHT_POINT && l.size > 0) return fail(ctx, RTU_ERR_STOCHASTIC, "light %u: soft shadow", i);
     }
     uint32_t n_shadow = 0;
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) n_shadow++;
     if (n_shadow > RTU_MAX_SHADOW_LIGHTS) return fail(ctx, RTU_ERR_UNSUPPORTED, "more than %d non-ambient lights", RTU_MAX_SHADOW_LIGHTS);
     if (s->n_materials > RTU_FI_MTL_MASK) return fail(ctx, RTU_ERR_UNSUPPORTED, "too many materials");
-    for (uint32_t i = 0; i < s->n_materials; i++)
-        if (s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0)
-            return fail(ctx, RTU_ERR_STOCHASTIC, "material %u: glossy bounce", i);
     for (uint32_t i = 0; i < s->n_nodes; i++) {
         const RtuNode& n = s->nodes[i];
         if (i == 0 ? n.parent != -1 : (n.parent < 0 || (uint32_t)n.parent >= i))
@@ -497,6 +497,10 @@ int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
     if (f->width <= 0 || f->height <= 0 || f->width > 65536 || f->height > 65536) return fail(ctx, RTU_ERR_ARG, "bad resolution");
     if (f->shard_count < 1 || f->shard_rank < 0 || f->shard_rank >= f->shard_count) return fail(ctx, RTU_ERR_ARG, "bad shard");
     if (f->max_bounce < 0 || f->max_bounce > RTU_MAX_BOUNCE) return fail(ctx, RTU_ERR_ARG, "max_bounce out of range");
+    if (f->samples < 0 || f->samples > 65536) return fail(ctx, RTU_ERR_ARG, "samples out of range");
+    if (f->samples == 0 && ctx->has_scene && (ctx->scene_stochastic || f->dof != 0))
+        return fail(ctx, RTU_ERR_STOCHASTIC, "the scene has %s: render it with frame.samples >= 1 (recipe S)",
+                    ctx->scene_stochastic ? ctx->stochastic_what.c_str() : "depth of field");
     return RTU_OK;
 }
 
@@ -569,7 +573,19 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels) {
     return RTU_OK;
 }
 
-int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
+// Halton (scene.h:130-139)
+float halton(int index, int base) {
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) {
+        r += f * (float)(i % base);
+        f /= (float)base;
+    }
+    return r;
+}
+
+// One launch sequence: the whole frame of recipe W, or sample `sample_index` of recipe S.
+int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0) {
     uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
     uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
     uint32_t n_tiles = tiles_x * bands;
@@ -595,6 +611,14 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
     a.tail_from = stats ? RTU_MAX_LEVELS : ctx->tail_hint;
+    if (frame->samples >= 1) {
+        const float pixelIncrement = (float)(1.0 / frame->samples);         // RenderFunctions.cpp:68
+        const float currentOffset = (float)sample_index * pixelIncrement;  // :80
+        a.sampling = 1;
+        a.sample_index = (uint32_t)sample_index;
+        a.pix_off_x = currentOffset + halton(sample_index, 4);              // :84, :96
+        a.pix_off_y = currentOffset + halton(sample_index, 5);              // :85, :96
+    }
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
@@ -658,6 +682,41 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     return RTU_OK;
 }
 
+// Recipe S: one launch sequence per sample, each checked for frame-capacity overflow before its image
+// (in d_out) is added to the accumulators; the mean goes back to d_out. Synchronises per sample.
+int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
+    const size_t pixels = (size_t)rtu_shard_rows(frame) * (size_t)frame->width;
+    if (pixels == 0) return RTU_OK;
+    if (pixels > ctx->acc_pixels) {
+        if (ctx->acc) (void)hipFree(ctx->acc);
+        if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);
+        ctx->acc = nullptr;
+        ctx->acc_hits = nullptr;
+        ctx->acc_pixels = 0;
+        RTU_HIP(ctx, hipMalloc((void**)&ctx->acc, pixels * sizeof(float4)));
+        RTU_HIP(ctx, hipMalloc((void**)&ctx->acc_hits, pixels * sizeof(uint32_t)));
+        ctx->acc_pixels = pixels;
+    }
+    int rounds = 0;
+    for (int i = 0; i < frame->samples; i++) {
+        for (;;) {
+            int rc = launch(ctx, frame, d_out, stream, zero_counters && i == 0, i);
+            if (rc != RTU_OK) return rc;
+            RTU_HIP(ctx, hipStreamSynchronize(stream));
+            bool overflow = false;
+            if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
+            if (!overflow) break;
+            if (++rounds > 4 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
+            if (frame->collect_stats) { i = 0; zero_counters = true; }  // the counters of the dropped pass are in the totals: start again
+        }
+        hipError_t e = (hipError_t)rtu_launch_accumulate(d_out, ctx->acc, ctx->acc_hits, (uint32_t)pixels, i == 0, stream);
+        if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    }
+    hipError_t e = (hipError_t)rtu_launch_resolve(ctx->acc, ctx->acc_hits, d_out, (uint32_t)pixels, (uint32_t)frame->samples, stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -715,6 +774,8 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
     if (ctx->tl) (void)hipFree(ctx->tl);
     if (ctx->fb) (void)hipFree(ctx->fb);
+    if (ctx->acc) (void)hipFree(ctx->acc);
+    if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -897,6 +958,13 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         for (int k = 0; k < 3; k++)
             if (mm.reflection[k] != 0 || mm.refraction[k] != 0) ctx->any_recursive_material = true;
     }
+    ctx->scene_stochastic = false;
+    ctx->stochastic_what.clear();
+    if (s->camera.dof != 0) { ctx->scene_stochastic = true; ctx->stochastic_what = "depth of field"; }
+    for (uint32_t i = 0; i < s->n_lights && !ctx->scene_stochastic; i++)
+        if (s->lights[i].type == RTU_LIGHT_POINT && s->lights[i].size > 0) { ctx->scene_stochastic = true; ctx->stochastic_what = "a soft shadow"; }
+    for (uint32_t i = 0; i < s->n_materials && !ctx->scene_stochastic; i++)
+        if (s->materials[i].reflection_glossiness > 0 || s->materials[i].refraction_glossiness > 0) { ctx->scene_stochastic = true; ctx->stochastic_what = "a glossy bounce"; }
     ctx->bvh_stack_needed = stack_needed;
     ctx->has_scene = true;
     return RTU_OK;
@@ -926,6 +994,10 @@ int rtu_frame_setup(const RtuCamera* cam, int width, int height, RtuFrameDesc* o
     out->origin[0] = origin.x; out->origin[1] = origin.y; out->origin[2] = origin.z;
     out->u[0] = u.x; out->u[1] = u.y; out->u[2] = u.z;
     out->v[0] = v.x; out->v[1] = v.y; out->v[2] = v.z;
+    // the lens disk of RenderFunctions.cpp:93: camera.up as given, normalize(dir x up)
+    out->lens_up[0] = up.x; out->lens_up[1] = up.y; out->lens_up[2] = up.z;
+    out->lens_right[0] = right.x; out->lens_right[1] = right.y; out->lens_right[2] = right.z;
+    out->dof = cam->dof;
     return RTU_OK;
 }
 
@@ -959,6 +1031,7 @@ int rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_
     if (!d_rgbz && rtu_shard_rows(frame) > 0) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
+    if (frame->samples >= 1) return render_sampled(ctx, frame, (float4*)d_rgbz, st, true);
     return launch(ctx, frame, (float4*)d_rgbz, st, true);
 }
 
@@ -993,6 +1066,11 @@ int rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, 
     RtuFrameDesc f = *frame;
     if (stats) f.collect_stats = 1;
     for (int attempt = 0;; attempt++) {
+        if (f.samples >= 1) {  // recipe S settles its capacities pass by pass
+            if ((rc = render_sampled(ctx, &f, ctx->fb, ctx->stream, true)) != RTU_OK) return rc;
+            RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
+        }
         rc = launch(ctx, &f, ctx->fb, ctx->stream, true);
         if (rc != RTU_OK) return rc;
         RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1031,7 +1109,7 @@ int rtu_time_render(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, vo
     hipStream_t st = (hipStream_t)hip_stream;
     RTU_HIP(ctx, hipEventRecord(ctx->ev0, st));
     for (int i = 0; i < iters; i++) {
-        rc = launch(ctx, frame, (float4*)d_rgbz, st, i == 0);
+        rc = frame->samples >= 1 ? render_sampled(ctx, frame, (float4*)d_rgbz, st, i == 0) : launch(ctx, frame, (float4*)d_rgbz, st, i == 0);
         if (rc != RTU_OK) return rc;
     }
     RTU_HIP(ctx, hipEventRecord(ctx->ev1, st));

@@ -104,7 +104,7 @@ struct DevScene {
 // children become frames of level L+1, and results are combined bottom-up in the
 // reference's exact term order.
 #define RTU_MAX_LEVELS        (RTU_MAX_BOUNCE + 1)
-#define RTU_MAX_SHADOW_LIGHTS 8   // non-ambient lights; more => RTU_ERR_UNSUPPORTED
+#define RTU_MAX_SHADOW_LIGHTS 13  // non-ambient lights (a ray id keeps 4 bits for lights + 3 secondary slots); more => RTU_ERR_UNSUPPORTED
 
 // frame info word (fa.w)
 #define RTU_FI_MTL_MASK   0x3FFFFu        // bits 0-17 material id
@@ -182,11 +182,19 @@ struct KernelArgs {
     int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
     uint32_t     n_meshes;
     int32_t      tail_from;         // recursion levels >= this are evaluated by k_tail (RTU_MAX_LEVELS: none)
+    // recipe S (frame.samples >= 1): one launch sequence per sample
+    uint32_t     sampling;          // 0: recipe W
+    uint32_t     sample_index;
+    float        pix_off_x, pix_off_y;  // currentOffset + Halton(index, 4 | 5), RenderFunctions.cpp:80-85,96
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine
 // bottom-up) on `stream`. Returns hipError_t as int.
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
+
+// recipe S: add one sample's image to the accumulators / write the mean
+int rtu_launch_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream);
+int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples, hipStream_t stream);
 
 int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);

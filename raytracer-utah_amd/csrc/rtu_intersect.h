@@ -975,10 +975,66 @@ __device__ __forceinline__ f3 env_sample(const DevScene& s, f3 dir) {
     return env_color_sample(s, s.env, s.env_map, uvw);
 }
 
-// sampledNormal of mtlFunctions.cpp:162-165 / :275-277 with SampleSphere(...,0) == (0,0,0)
-__device__ __forceinline__ f3 sampled_normal(f3 p, f3 N) {
+// ---- sample streams of recipe S (include/rtu_render.h states the contract) -----------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rand31(uint32_t key, uint32_t purpose) { return mix32(key ^ mix32(purpose * 0x9e3779b9U + 0x85ebca6bU)) >> 1; }
+__device__ __forceinline__ uint32_t sample_key(uint32_t pixel, uint32_t sample) { return mix32(mix32(pixel + 0x68bc21ebU) ^ (sample * 0x9e3779b9U + 1U)); }
+__device__ __forceinline__ uint32_t child_key(uint32_t key, uint32_t slot) { return mix32(key + (slot + 1U) * 0x632be5abU); }
+#define RTU_DRAW_LENS  0u
+#define RTU_DRAW_LIGHT 16u
+#define RTU_DRAW_REFR1 0x10000u
+#define RTU_DRAW_REFR2 0x20000u
+#define RTU_DRAW_REFL  0x30000u
+#define RTU_RAND_MAX_F 2147483648.0f                  // static_cast<float>(RAND_MAX)
+#define RTU_THETA_DIV  ((float)(2147483647 / (2 * 3.14159265358979323846)))  // static_cast<float>(RAND_MAX/(2 * M_PI))
+// The key of the Shade() call a frame stands for, and whether the frame is sampled at all.
+struct Smp {
+    bool on;
+    uint32_t key;
+};
+
+// sin and cos of sampleTheta in [0, 2 pi]: binary64, IEEE operations only, the sequence of the oracle's
+// portable_sincos (quadrant reduction with a two-part pi/2, the fdlibm kernel polynomials).
+__device__ __forceinline__ void portable_sincos(float t, float& sn, float& cs) {
+    const double x = (double)t;
+    const double kd = floor(x * 6.36619772367581382433e-01 + 0.5);
+    const int k = (int)kd;
+    const double y = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double y2 = y * y;
+    const double ps = -1.66666666666666324348e-01 + y2 * (8.33333333332248946124e-03 + y2 * (-1.98412698298579493134e-04 +
+                      y2 * (2.75573137070700676789e-06 + y2 * (-2.50507602534068634195e-08 + y2 * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + y2 * (-1.38888888888741095749e-03 + y2 * (2.48015872894767294178e-05 +
+                      y2 * (-2.75573143513906633035e-07 + y2 * (2.08757232129817482790e-09 + y2 * -1.13596475577881948265e-11))));
+    const double s = y + (y * y2) * ps;
+    const double c = 1.0 - (0.5 * y2 - (y2 * y2) * pc);
+    const double so = (k & 1) ? c : s, co = (k & 1) ? s : c;
+    sn = (float)((k & 2) ? -so : so);
+    cs = (float)((((k + 1) & 2) != 0) ? -co : co);
+}
+
+// SampleSphere (RenderFunctions.cpp:282-301): a point of the cube [-radius, radius]^3, drawn again
+// while it lies outside the sphere (at most 64 attempts).
+__device__ __forceinline__ f3 sample_sphere(float radius, uint32_t key, uint32_t base) {
+    f3 offset = mk3(0, 0, 0);
+    const float div = RTU_RAND_MAX_F / (radius * 2);
+    for (uint32_t attempt = 0; attempt < 64u; attempt++) {
+        const float rand1 = -radius + (float)rand31(key, base + 3u * attempt) / div;       // :291
+        const float rand2 = -radius + (float)rand31(key, base + 3u * attempt + 1u) / div;  // :292
+        const float rand3 = -radius + (float)rand31(key, base + 3u * attempt + 2u) / div;  // :293
+        offset = mk3(rand1, rand2, rand3);
+        if (!(len3(offset) > radius)) break;  // :297
+    }
+    return offset;
+}
+// sampledNormal of mtlFunctions.cpp:162-165 / :225-227 / :275-277; SampleSphere(..., 0) == (0,0,0)
+__device__ __forceinline__ f3 sampled_normal(f3 p, f3 N, Smp smp, float glossiness, uint32_t base) {
     f3 sampleOrigin = p + N;
-    return norm3((sampleOrigin + mk3(0, 0, 0)) - p);
+    f3 sampledOffset = mk3(0, 0, 0);
+    if (smp.on && glossiness > 0) sampledOffset = sample_sphere(glossiness, smp.key, base);
+    return norm3((sampleOrigin + sampledOffset) - p);
 }
 __device__ __forceinline__ f3 reflect_dir(f3 dir, f3 sn) {  // :207, :239, :280
     float k = 2 * dot3(dir, sn);
@@ -988,15 +1044,18 @@ __device__ __forceinline__ f3 reflect_dir(f3 dir, f3 sn) {  // :207, :239, :280
 // Snell / Fresnel terms of mtlFunctions.cpp:168-203,236-237. Recomputed from the
 // frame whenever a stage resumes (pure ALU) instead of being saved.
 struct Refr {
-    f3    sn;          // sampled normal
+    f3    sn;          // sampled normal (:162-165)
+    f3    sn2;         // the second sample (:225-227), which the refracted and the Fresnel ray use
     float cosTheta1;   // after clamping
     float sinTheta2, cosTheta2;
     float n1, n2;
     f3    SVector;
 };
-__device__ __forceinline__ Refr refraction_terms(f3 dir, f3 p, f3 N, bool front, float ior) {
+__device__ __forceinline__ Refr refraction_terms(f3 dir, f3 p, f3 N, bool front, float ior, Smp smp, float glossiness) {
     Refr r;
-    r.sn = sampled_normal(p, N);
+    r.sn = sampled_normal(p, N, smp, glossiness, RTU_DRAW_REFR1);
+    r.sn2 = r.sn;
+    if (smp.on && glossiness > 0) r.sn2 = sampled_normal(p, N, smp, glossiness, RTU_DRAW_REFR2);
     float cosTheta1 = dot3(r.sn, -dir);
     float sinTheta1 = (float)sqrt(1 - (double)cosTheta1 * (double)cosTheta1);  // :169 (pow(x,2) is exact in fp64)
     if (sinTheta1 > 1) sinTheta1 = 1.0f;

@@ -18,6 +18,8 @@ EXTRA_TAGS = ["p1test_200x150", "p2_200x150", "p3box_200x150", "p5_200x150", "p5
 SMALL_TAGS = SMALL_TAGS + EXTRA_TAGS
 ALL_TAGS = SMALL_TAGS + FULL_TAGS
 TEX_TAGS = ["p7_200x150"]  # textured
+# stochastic effects, recipe S: glossy + soft + textured; depth of field; glossy + soft; 12 soft lights + glossy refraction; teapot + soft
+SAMPLED_TAGS = ["p10_s4_160x120", "p9_s3_160x120", "p11gs_s2_160x90", "p11x86_s1_120x90", "teapot1_s2_160x90"]
 
 
 def pytest_configure(config):

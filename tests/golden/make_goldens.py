@@ -4,7 +4,7 @@
 Authoring container only (needs /root/reference and oracle/_ref/ref_render, built
 by `make -C oracle`). For every BASELINE config it runs the reference's own
 Trace/Shade functions through oracle/ref_harness/driver.cpp ("recipe W",
-SURVEY.md §8c) and stores DATA only:
+SURVEY.md §8c; "recipe S" for the scenes with stochastic effects) and stores DATA only:
 
   scene.rtus.gz   flattened scene (input), serialised from the reference's
                   in-memory scene graph after LoadScene()
@@ -45,6 +45,15 @@ CONFIGS = [
     ("p13_200x150", "Project13/scene.xml", 200, 150, True),
     # textures ("next" row f2): checkerboards, two 1024x1024 PNGs (mesh diffuse, background, environment)
     ("p7_200x150", "Project7/scene.xml", 200, 150, True),
+    # stochastic effects ("next" row f1), recipe S: the 7th field is samples per pixel. The reference is built
+    # with rand() wrapped to the sequential sample stream (oracle/ref_harness/Makefile), so these are
+    # reproducible: glossy reflection + refraction + a size-5 light + textures; depth of field + textures;
+    # glossy reflections + a size-5 light; twelve size-1 lights + glossy refraction; the teapot under a size-5 light
+    ("p10_s4_160x120", "Project10/scene.xml", 160, 120, True, 4),
+    ("p9_s3_160x120", "Project9/scene.xml", 160, 120, True, 3),
+    ("p11gs_s2_160x90", "Project11/scene_glossy_soft.xml", 160, 90, True, 2),
+    ("p11x86_s1_120x90", "Project11/scene_86.xml", 120, 90, True, 1),
+    ("teapot1_s2_160x90", "Teapot/scene.xml", 160, 90, True, 2),
 ]
 
 
@@ -54,10 +63,12 @@ def sha(a):
 
 def main():
     only = set(sys.argv[1:])
-    for tag, scene, W, H, full in CONFIGS:
+    for cfg in CONFIGS:
+        tag, scene, W, H, full = cfg[:5]
+        spp = cfg[5] if len(cfg) > 5 else 0
         if only and tag not in only:
             continue
-        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"])
+        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"] + ([str(spp)] if spp else []))
         src = os.path.join(REPO, "oracle", "_ref", "out", tag)
         dst = os.path.join(HERE, tag)
         os.makedirs(dst, exist_ok=True)
@@ -72,7 +83,8 @@ def main():
         z8 = np.fromfile(os.path.join(src, "zbuffer.u8"), np.uint8).reshape(H, W)
         stats = json.load(open(os.path.join(src, "stats.json")))
         meta = {
-            "scene": scene, "width": W, "height": H, "recipe": "W",
+            "scene": scene, "width": W, "height": H, "recipe": "S" if spp else "W", "spp": spp,
+            "stream": "sequential" if spp else None,
             "primary": stats["primary"], "primary_hits": stats["primary_hits"],
             "secondary": stats["secondary"], "shadow": stats["shadow"],
             "sha256_z_f32": sha(z), "sha256_rgb_f32": sha(rgb),

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFERENCE, SMALL_TAGS, TEX_TAGS, read_png, sha256
+from conftest import REFERENCE, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, read_png, sha256
 
 
 @pytest.mark.parametrize("tag", SMALL_TAGS + TEX_TAGS)
@@ -111,3 +111,92 @@ def test_oracle_vs_live_reference_build(pkg, orc, tmp_path):
     rgb = np.fromfile(tmp_path / "rgb.f32", np.float32).reshape(H, W, 3)
     assert np.array_equal(out[..., 3].view(np.uint32), z.view(np.uint32))
     assert np.array_equal(out[..., :3].view(np.uint32), rgb.view(np.uint32))
+
+
+# ---- recipe S: stochastic effects -------------------------------------------------
+@pytest.mark.parametrize("tag", SAMPLED_TAGS)
+def test_oracle_recipe_s_bit_exact_vs_reference_golden(pkg, orc, golden, tag):
+    """The goldens come from the reference built with rand() wrapped to the sequential sample stream
+    (oracle/ref_harness): the restatement of the sample loop, soft shadows, glossy bounces and depth of
+    field must reproduce every bit of z and linear RGB, and fire the same rays."""
+    g = golden(tag)
+    assert g.meta["recipe"] == "S" and g.meta["stream"] == "sequential"
+    out, st = orc.render_samples(g.scene(pkg), g.width, g.height, g.meta["spp"], stream=orc.STREAM_SEQUENTIAL,
+                                 trig=orc.TRIG_LIBM, threads=4)
+    assert np.array_equal(out[..., 3].view(np.uint32), g.npz["z"].view(np.uint32)), "z differs"
+    assert np.array_equal(out[..., :3].view(np.uint32), g.npz["rgb"].view(np.uint32)), "linear RGB differs"
+    assert (st["primary_rays"], st["primary_hits"], st["secondary_rays"], st["shadow_rays"]) == (
+        g.meta["primary"], g.meta["primary_hits"], g.meta["secondary"], g.meta["shadow"])
+    rgb8, _, zimg = orc.postprocess(out)
+    assert np.array_equal(rgb8, g.npz["result_u8"]) and np.array_equal(zimg, g.npz["zbuffer_u8"])
+
+
+def test_portable_sincos_within_one_ulp_of_libm(orc):
+    """The device cannot call libm's sinf/cosf; oracle and device share a binary64 evaluation instead.
+    It must stay within 1 ulp of the float results the reference's calls give (and equal them almost always)."""
+    rng = np.random.default_rng(5)
+    t = np.concatenate([rng.random(400000, dtype=np.float32) * np.float32(2 * np.pi),
+                        np.array([0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 1e-30, 6.2831855], np.float32)])
+    s, c = orc.portable_sincos(t)
+    for got, want in ((s, np.sin(t.astype(np.float64))), (c, np.cos(t.astype(np.float64)))):
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(got.astype(np.float64) - want) <= 0.5000001 * np.maximum(ulp, 1e-45)), "not correctly rounded"
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = ctypes.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [ctypes.c_float]
+    sub = t[:20000]
+    ls = np.array([libm.sinf(float(x)) for x in sub], np.float32)
+    lc = np.array([libm.cosf(float(x)) for x in sub], np.float32)
+    for got, want in ((s[:20000], ls), (c[:20000], lc)):
+        d = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert d.max() <= 1 and (d != 0).mean() < 0.02
+
+
+def test_recipe_s_portable_trig_changes_few_pixels(pkg, orc, golden):
+    """Depth of field feeds sin/cos into the primary ray: with the portable evaluation a handful of pixels
+    move by an ulp-sized lens offset; everything else is still the reference's image bit for bit."""
+    g = golden("p9_s3_160x120")
+    out, _ = orc.render_samples(g.scene(pkg), g.width, g.height, g.meta["spp"], stream=orc.STREAM_SEQUENTIAL,
+                                trig=orc.TRIG_PORTABLE, threads=4)
+    same = out[..., 3].view(np.uint32) == g.npz["z"].view(np.uint32)
+    assert same.mean() > 0.99
+    assert np.abs(out[..., :3] - g.npz["rgb"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["p10_s4_160x120", "p11gs_s2_160x90"])
+def test_recipe_s_keyed_stream_is_the_same_estimator(pkg, orc, golden, tag):
+    """The keyed stream (what the device follows) draws other numbers than the sequential one, from the
+    same distributions: z is identical without depth of field, and the image means agree to within the noise."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    spp = 16
+    a, sa = orc.render_samples(scene, g.width, g.height, spp, stream=orc.STREAM_SEQUENTIAL, threads=8)
+    b, sb = orc.render_samples(scene, g.width, g.height, spp, stream=orc.STREAM_KEYED, threads=8)
+    assert np.array_equal(a[..., 3].view(np.uint32), b[..., 3].view(np.uint32))
+    assert not np.array_equal(a[..., :3], b[..., :3])
+    ma, mb = a[..., :3].mean(), b[..., :3].mean()
+    assert abs(ma - mb) < 0.01 * ma
+    assert abs(sa["shadow_rays"] - sb["shadow_rays"]) < 0.01 * sa["shadow_rays"]
+    # threads and row ranges do not change a keyed image
+    c, _ = orc.render_samples(scene, g.width, g.height, spp, stream=orc.STREAM_KEYED, threads=3, row0=17, nrows=9)
+    assert np.array_equal(c.view(np.uint32), b[17:26].view(np.uint32))
+
+
+def test_sample_stream_known_answers(orc):
+    """The integer hash of include/rtu_render.h, pinned by value so that oracle, device and documentation
+    cannot drift apart silently."""
+    def mix32(x):
+        x &= 0xFFFFFFFF
+        x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+        x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+        x ^= x >> 16
+        return x
+    for key, idx in ((0, 0), (1, 2), (0xdeadbeef, 0x30005), (123456789, 17)):
+        want = mix32(key ^ mix32((idx * 0x9e3779b9 + 0x85ebca6b) & 0xFFFFFFFF)) >> 1
+        assert orc.lib.rtu_oracle_rand31(key, idx) == want
+    for pix, smp in ((0, 0), (1919 + 1920 * 1079, 63)):
+        want = mix32(mix32((pix + 0x68bc21eb) & 0xFFFFFFFF) ^ ((smp * 0x9e3779b9 + 1) & 0xFFFFFFFF))
+        assert orc.lib.rtu_oracle_sample_key(pix, smp) == want
+    for key, slot in ((5, 0), (0xffffffff, 2)):
+        assert orc.lib.rtu_oracle_child_key(key, slot) == mix32((key + (slot + 1) * 0x632be5ab) & 0xFFFFFFFF)

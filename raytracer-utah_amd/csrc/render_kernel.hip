@@ -39,6 +39,12 @@
 
 namespace {
 
+// Feature mask of a kernel instantiation (template parameter TEX): bit 0 the scene is textured (uvw
+// carried, maps sampled), bit 1 the frame is sampled (recipe S: sample streams, soft shadows, glossy
+// bounces, lens). Recipe W on an untextured scene compiles to exactly the code it had before either existed.
+#define TEXD ((TEX & 1) != 0)
+#define SMPD ((TEX & 2) != 0)
+
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
 // k_trace slot selection bits
 enum { SEL_SHADOW = 1, SEL_MAIN = 2, SEL_A = 4, SEL_C = 8, SEL_A_NEEDS_B = 16 };
@@ -112,18 +118,18 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
 }
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
-template <bool TEX>
+template <int TEX>
 __device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp) {
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
     uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
     if (front && s.n_lights > 0) info |= RTU_FI_SH;                      // mtlFunctions.cpp:125
     if (bounce > 0) {                                                   // :158
-        if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
+        if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
             info |= RTU_FI_MAIN;
             Refr r = refraction_terms(dir, p, N, front, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
             if (r.sinTheta2 > 1) info |= RTU_FI_TIR;                    // :205
         }
-        if (not_black(mtl_color<TEX>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw))) info |= RTU_FI_C;  // :273
+        if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw))) info |= RTU_FI_C;  // :273
     }
     return info;
 }
@@ -143,9 +149,10 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
 
 // The key of the sample streams of the Shade() call a frame stands for (recipe S): level 0 frames
 // carry their pixel in fb.w, deeper frames their key.
+template <int TEX>
 __device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) {
     Smp smp;
-    smp.on = a.sampling != 0;
+    smp.on = SMPD;
     smp.key = 0;
     if (smp.on) {
         const uint32_t w = __float_as_uint(fbw);
@@ -208,7 +215,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
 }
 
 // ---- the primary ray of one pixel -------------------------------------------------------
-template <int STACK, bool STATS, bool DEFER, bool COOP, bool TEX>
+template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
 __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t pix, uint32_t shard,
                                               uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
                                               const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
@@ -222,7 +229,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     int mid = -1;
     deferred = false;
     Smp smp;
-    smp.on = a.sampling != 0;
+    smp.on = SMPD;
     smp.key = 0;
     if (valid) {
         float ox = 0.5f, oy = 0.5f;  // recipe W: the pixel centre
@@ -243,10 +250,10 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + ox)) + ld3(a.frame.v) * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEX>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
         if (!deferred && leader) {
             if (!hit) {
-                f3 bg = background_sample<TEX>(s, x, y);  // :145
+                f3 bg = background_sample<TEXD>(s, x, y);  // :145
                 a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
             } else {
                 RTU_CNT(prim_hit);
@@ -280,7 +287,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
         if (fl < lv.cap_s) {
             const uint32_t idx = fl + shard * lv.cap_s;
-            if (TEX) lv.fuv[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+            if (TEXD) lv.fuv[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
             lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
@@ -294,7 +301,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
-template <int STACK, bool STATS, bool TEX>
+template <int STACK, bool STATS, int TEX>
 __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
     const Stamp stamp(a, RTU_TL_PRIMARY);
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
@@ -329,7 +336,7 @@ __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nod
 }
 
 // stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
-template <int STACK, bool TEX>
+template <int STACK, int TEX>
 __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2);
     __shared__ uint32_t s_stack[STACK * 64];
@@ -357,7 +364,7 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
 
 // stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
 // (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
-template <int STACK, bool TEX>
+template <int STACK, int TEX>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2C);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
 // ---- one ray of one frame ------------------------------------------------------------------
 // slot < nsl: shadow ray of non-ambient light `slot`; else secondary ray slot - nsl.
 // Returns true if the ray was deferred (DEFER only).
-template <int STACK, bool STATS, bool DEFER, bool COOP, bool TEX>
+template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
 __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt,
                                           bool leader = true, const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
@@ -415,9 +422,9 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         f3 lvec = ld3(l.vec);
         if (l.type == RTU_LIGHT_DIRECT) {
             r.dir = -lvec;
-        } else if (a.sampling && l.size > 0) {
+        } else if (SMPD && l.size > 0) {
             // soft shadow: one ray towards a random point of the light's disk
-            const Smp smp = frame_smp(a, L, lv.fb[f].w);
+            const Smp smp = frame_smp<TEX>(a, L, lv.fb[f].w);
             const float sampleR = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li) / (RTU_RAND_MAX_F / l.size);  // :47
             const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li + 1u) / RTU_THETA_DIV;     // :48
             float sn, cs;
@@ -446,13 +453,13 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         }
         const float4 fb = lv.fb[f], fc = lv.fc[f];
         const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-        r.dir = secondary_dir(sslot, info, dir, p, N, as_const(s.materials)[info & RTU_FI_MTL_MASK], frame_smp(a, L, fb.w));
+        r.dir = secondary_dir(sslot, info, dir, p, N, as_const(s.materials)[info & RTU_FI_MTL_MASK], frame_smp<TEX>(a, L, fb.w));
         RTU_CNT(sec);
     }
     Hit h;
     fresh_hit(h, tmax);
     bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEX>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
+    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
     if (DEFER && deferred) return true;
     if (!leader) return false;
     if (is_shadow) {
@@ -464,13 +471,13 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
         slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
         slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
-        if (TEX) lv.fsuv[(size_t)f * 3 + sslot] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+        if (TEXD) lv.fsuv[(size_t)f * 3 + sslot] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
     }
     return false;
 }
 
 // stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
-template <int STACK, bool STATS, bool TEX>
+template <int STACK, bool STATS, int TEX>
 __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
@@ -523,7 +530,7 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
 }
 
 // stage 2, long lists: one lane per deferred ray
-template <int STACK, bool TEX>
+template <int STACK, int TEX>
 __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
     __shared__ uint32_t s_stack[STACK * 64];
@@ -545,7 +552,7 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
 }
 
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
-template <int STACK, bool TEX>
+template <int STACK, int TEX>
 __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
@@ -575,7 +582,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
 // ------------------------------------------------------------------------------------
 // MtlBlinn::Shade combination (mtlFunctions.cpp:205-291) once every child result is
 // known. st* >= 0 or RTU_CH_WHITE: that ray hit and ret* holds Shade() of the hit.
-template <bool TEX>
+template <int TEX>
 __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMaterial& m, uint32_t info, f3 direct, f3 dir, f3 p,
                                        f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront, f3 uvw,
                                        Smp smp) {
@@ -583,11 +590,11 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
     const int mtl = (int)(info & RTU_FI_MTL_MASK);
     // environment.SampleEnvironment(direction of the ray that missed); a constant without an environment map
     auto env_at = [&](int slot) {
-        return (TEX && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m, smp)) : ld3(s.environment);
+        return (TEXD && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m, smp)) : ld3(s.environment);
     };
     f3 result = direct;
     if (info & RTU_FI_MAIN) {
-        const f3 refraction = mtl_color<TEX>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw), absorption = ld3(m.absorption);
+        const f3 refraction = mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw), absorption = ld3(m.absorption);
         const bool mainHit = stMain >= 0 || stMain == RTU_CH_WHITE;
         if (info & RTU_FI_TIR) {
             if (mainHit) result = result + absorb(RTU_BIGFLOAT, absorption) * retMain;  // :210-221 (z of a fresh HitInfo)
@@ -606,7 +613,7 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
     }
     if (info & RTU_FI_C) {
         const bool cHit = stC >= 0 || stC == RTU_CH_WHITE;
-        if (cHit) result = result + mtl_color<TEX>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw) * retC;  // :286
+        if (cHit) result = result + mtl_color<TEXD>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw) * retC;  // :286
         else result = result + env_at(SLOT_C) * ld3(m.reflection);  // :289: GetColor()
     }
     return result;
@@ -615,7 +622,7 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
 // One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
 // lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
 // a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
-template <bool STATS, bool TEX>
+template <bool STATS, int TEX>
 __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
                                               uint32_t f, int st_out[3]) {
     const DevScene& s = a.scene;
@@ -631,9 +638,9 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
     const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
-    const Smp smp = frame_smp(a, L, fb.w);
+    const Smp smp = frame_smp<TEX>(a, L, fb.w);
     f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
-    if (TEX && active) {
+    if (TEXD && active) {
         const float4 t = lv.fuv[f];
         uvw = mk3(t.x, t.y, t.z);
     }
@@ -642,8 +649,8 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     f3 direct = mk3(0, 0, 0);
     if (active && (info & RTU_FI_SH)) {
         const int mtl = (int)(info & RTU_FI_MTL_MASK);
-        const f3 diffuse = mtl_color<TEX>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
-        const f3 specular = mtl_color<TEX>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
+        const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
+        const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
         uint32_t j = 0;  // index among the non-ambient lights
         const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
         for (uint32_t i = 0; i < s.n_lights; i++) {
@@ -739,7 +746,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
             csmp.key = smp.on ? child_key(smp.key, (uint32_t)k) : 0u;
             const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
             f3 cuvw = mk3(0, 0, 0);
-            if (TEX) {
+            if (TEXD) {
                 const float4 t = lv.fsuv[(size_t)f * 3 + k];
                 cuvw = mk3(t.x, t.y, t.z);
                 nx.fuv[idx] = t;
@@ -796,7 +803,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     }
 }
 
-template <bool STATS, bool TEX>
+template <bool STATS, int TEX>
 __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
     const LevelBuffers& lv = a.lv[L];
@@ -814,7 +821,7 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
 
 // Frames that waited for children: combine bottom-up.
 // One frame that waited for its children (the body of k_combine; also used by k_tail).
-template <bool TEX>
+template <int TEX>
 __device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32_t f) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
@@ -843,17 +850,17 @@ __device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32
         bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
     }
     f3 uvw = mk3(0, 0, 0);
-    if (TEX) {
+    if (TEXD) {
         const float4 t = lv.fuv[f];
         uvw = mk3(t.x, t.y, t.z);
     }
     const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw,
-                               frame_smp(a, L, fb.w));
+                               frame_smp<TEX>(a, L, fb.w));
     if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
     else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
 }
 
-template <bool TEX>
+template <int TEX>
 __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_COMBINE0 + L);
     const LevelBuffers& lv = a.lv[L];
@@ -888,7 +895,7 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
 // then the combines bottom-up. Correct for any number of frames (the count is only a hint for
 // the host's choice); the regular k_combine of levels < Ls follow.
 #define RTU_TAIL_CAP 256  // frames of one level in one subtree: at most 3^4 = 81 for a cut at level 1, 243 in theory
-template <bool TEX>
+template <int TEX>
 __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * Ls);
     __shared__ uint32_t s_stack[8 * RTU_STACK8];
@@ -1036,7 +1043,7 @@ __global__ void k_selftest_prims(unsigned long long n_rays, unsigned long long s
     if (bad) atomicAdd(mismatches, bad);
 }
 
-template <int STACK, bool TEX>
+template <int STACK, int TEX>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
@@ -1122,16 +1129,21 @@ int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed
     return (int)hipGetLastError();
 }
 
+template <int FEAT>
+static int launch_feat(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
+    if (bvh_stack_needed <= 16) return launch_all<16, FEAT>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 24) return launch_all<24, FEAT>(args, n_tiles, stats, stream);
+    if (bvh_stack_needed <= 32) return launch_all<32, FEAT>(args, n_tiles, stats, stream);
+    return launch_all<RTU_MAX_BVH_STACK, FEAT>(args, n_tiles, stats, stream);
+}
+
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
-    // textured scenes run their own instantiation: untextured ones carry no uvw and sample nothing
-    if (args.scene.textured) {
-        if (bvh_stack_needed <= 16) return launch_all<16, true>(args, n_tiles, stats, stream);
-        if (bvh_stack_needed <= 24) return launch_all<24, true>(args, n_tiles, stats, stream);
-        if (bvh_stack_needed <= 32) return launch_all<32, true>(args, n_tiles, stats, stream);
-        return launch_all<RTU_MAX_BVH_STACK, true>(args, n_tiles, stats, stream);
+    // textured scenes and sampled frames run their own instantiations: the others carry no uvw, sample
+    // nothing and draw nothing
+    switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : 0)) {
+        case 0: return launch_feat<0>(args, n_tiles, bvh_stack_needed, stats, stream);
+        case 1: return launch_feat<1>(args, n_tiles, bvh_stack_needed, stats, stream);
+        case 2: return launch_feat<2>(args, n_tiles, bvh_stack_needed, stats, stream);
+        default: return launch_feat<3>(args, n_tiles, bvh_stack_needed, stats, stream);
     }
-    if (bvh_stack_needed <= 16) return launch_all<16, false>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 24) return launch_all<24, false>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 32) return launch_all<32, false>(args, n_tiles, stats, stream);
-    return launch_all<RTU_MAX_BVH_STACK, false>(args, n_tiles, stats, stream);
 }

@@ -87,6 +87,12 @@ typedef struct RtuRenderJob RtuRenderJob;
 RtuRenderJob* rtu_begin_render(const RtuScene* scene, RtuImage* img,
                                const int* device_ids, int n_devices,
                                const char* result_png, const char* zbuffer_png);
+/* The same with `samples` per pixel (RtuFrameDesc.samples in rtu_render.h): 0 is rtu_begin_render; S >= 1
+ * renders recipe S, which scenes with soft shadows, glossy bounces or depth of field need (the reference's
+ * Render() hard-codes 1024 samples, RenderFunctions.cpp:27). */
+RtuRenderJob* rtu_begin_render_sampled(const RtuScene* scene, RtuImage* img,
+                                       const int* device_ids, int n_devices, int samples,
+                                       const char* result_png, const char* zbuffer_png);
 void      rtu_stop_render(RtuRenderJob* job);      /* cooperative cancel between bands */
 int       rtu_render_wait(RtuRenderJob* job);      /* join; 0 or negative error code */
 void      rtu_render_job_free(RtuRenderJob* job);

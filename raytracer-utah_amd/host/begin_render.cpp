@@ -24,7 +24,7 @@ struct RtuRenderJob {
 
 namespace {
 
-void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::vector<int> devices,
+void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::vector<int> devices, int samples,
              std::string result_png, std::string zbuffer_png) {
     const int W = rtu_image_width(img), H = rtu_image_height(img);
     const int G = (int)devices.size();
@@ -48,6 +48,7 @@ void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::ve
         if (rc != RTU_OK) break;
         frames[g].shard_rank = g;
         frames[g].shard_count = G;
+        frames[g].samples = samples;
         size_t bytes = (size_t)rtu_shard_rows(&frames[g]) * W * 4 * sizeof(float);
         if (bytes == 0) continue;
         dbuf[g] = rtu_device_alloc(ctxs[g], bytes);
@@ -60,6 +61,12 @@ void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::ve
         if (job->cancel.load()) { rc = RTU_ERR_ARG; job->error = "cancelled"; break; }
         int rows = rtu_shard_rows(&frames[g]);
         if (rows == 0) continue;
+        // more Shade() frames than provisioned: the context has grown its buffers, render the shard again
+        for (int round = 0; (rc = rtu_frame_status(ctxs[g])) == RTU_ERR_CAPACITY && round < 16; round++) {
+            rc = rtu_render_frame_device(ctxs[g], &frames[g], dbuf[g], nullptr);
+            if (rc != RTU_OK) break;
+        }
+        if (rc != RTU_OK) { job->error = rtu_last_error(ctxs[g]); break; }
         shard.resize((size_t)rows * W * 4);
         rc = rtu_copy_to_host(ctxs[g], shard.data(), dbuf[g], shard.size() * sizeof(float));
         if (rc != RTU_OK) { job->error = rtu_last_error(ctxs[g]); break; }
@@ -85,17 +92,22 @@ void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::ve
 
 extern "C" {
 
-RtuRenderJob* rtu_begin_render(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices,
-                               const char* result_png, const char* zbuffer_png) {
-    if (!scene || !img || !device_ids || n_devices < 1) {
+RtuRenderJob* rtu_begin_render_sampled(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices, int samples,
+                                       const char* result_png, const char* zbuffer_png) {
+    if (!scene || !img || !device_ids || n_devices < 1 || samples < 0) {
         rtu::set_error("rtu_begin_render: bad arguments");
         return nullptr;
     }
     RtuRenderJob* job = new RtuRenderJob;
     std::vector<int> devs(device_ids, device_ids + n_devices);
-    job->thread = std::thread(run_job, job, rtu_scene_desc(scene), img, devs, std::string(result_png ? result_png : ""),
+    job->thread = std::thread(run_job, job, rtu_scene_desc(scene), img, devs, samples, std::string(result_png ? result_png : ""),
                               std::string(zbuffer_png ? zbuffer_png : ""));
     return job;  // returns immediately, as BeginRender() must
+}
+
+RtuRenderJob* rtu_begin_render(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices,
+                               const char* result_png, const char* zbuffer_png) {
+    return rtu_begin_render_sampled(scene, img, device_ids, n_devices, 0, result_png, zbuffer_png);
 }
 
 void rtu_stop_render(RtuRenderJob* job) {

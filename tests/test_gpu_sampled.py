@@ -138,3 +138,26 @@ def test_sampled_device_entry_and_timing(pkg, ctx, golden):
     ms = ctx.time_render(fr, d, None, 3)
     assert ms > 0
     pkg.hip.rtu_device_free(ctx._h, d)
+
+
+def test_begin_render_sampled_dropin(pkg, orc, golden, tmp_path):
+    """The BeginRender()-style entry with samples: the PNGs equal the oracle's post-processed image (z image
+    exact, RGB +-1); without samples the same scene is refused with RTU_ERR_STOCHASTIC."""
+    from conftest import read_png
+    g = golden("p10_s4_160x120")
+    scene = g.scene(pkg)
+    spp = g.meta["spp"]
+    cpu, _ = orc.render_samples(scene, g.width, g.height, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=8)
+    c8, _, cz8 = orc.postprocess(cpu)
+    img = pkg.Image(g.width, g.height)
+    devs = (ctypes.c_int * 1)(0)
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    job = pkg.host.rtu_begin_render_sampled(scene._h, img._h, devs, 1, spp, rp.encode(), zp.encode())
+    assert job
+    assert pkg.host.rtu_render_wait(job) == 0, pkg.host.rtu_host_last_error()
+    pkg.host.rtu_render_job_free(job)
+    assert np.array_equal(read_png(zp), cz8)
+    assert np.abs(read_png(rp).astype(np.int32) - c8.astype(np.int32)).max() <= RGB8_TOL
+    job = pkg.host.rtu_begin_render(scene._h, img._h, devs, 1, None, None)
+    assert pkg.host.rtu_render_wait(job) == pkg.RTU_ERR_STOCHASTIC
+    pkg.host.rtu_render_job_free(job)

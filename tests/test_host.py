@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ALL_TAGS, REFERENCE, REPO, SMALL_TAGS, TEX_TAGS, read_png
+from conftest import ALL_TAGS, REFERENCE, REPO, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, read_png
 
 MAC_PREFIX = "/Users/Peter/GitRepos/RayTracer-Utah"
 SCENES = {
@@ -20,6 +20,9 @@ SCENES = {
     "p5_200x150": "Project5/scene.xml", "p5low_200x150": "Project5/scene-low.xml",
     "p11simple_200x150": "Project11/scene_simple.xml", "p13_200x150": "Project13/scene.xml",
     "p7_200x150": "Project7/scene.xml",
+    "p10_s4_160x120": "Project10/scene.xml", "p9_s3_160x120": "Project9/scene.xml",
+    "p11gs_s2_160x90": "Project11/scene_glossy_soft.xml", "p11x86_s1_120x90": "Project11/scene_86.xml",
+    "teapot1_s2_160x90": "Teapot/scene.xml",
 }
 
 
@@ -82,7 +85,7 @@ def test_blob_rejects_garbage(pkg, golden):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="scene files only exist in the authoring container")
-@pytest.mark.parametrize("tag", ALL_TAGS + TEX_TAGS)
+@pytest.mark.parametrize("tag", ALL_TAGS + TEX_TAGS + SAMPLED_TAGS)
 def test_loader_matches_reference_scene_values(pkg, golden, tag):
     """Own XML + OBJ reader + BVH build vs the blob dumped from the reference's in-memory
     scene graph after ITS LoadScene(): every float of every node/material/light/camera,

@@ -147,6 +147,22 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
     return norm3((-t.sn2) * t.cosTheta2 + t.SVector * t.sinTheta2);  // :229
 }
 
+// A sampled launch renders a.batch consecutive samples of the frame at once (longer ray lists fill the chip
+// better): its pixel index space is [sample in batch][pixel of the shard]. pix -> global x, y and the
+// sample's place in the batch.
+template <int TEX>
+__device__ __forceinline__ void pixel_of(const KernelArgs& a, uint32_t pix, int& x, int& y, uint32_t& sidx) {
+    sidx = 0;
+    uint32_t lp = pix;
+    if (SMPD) {
+        sidx = pix / a.batch_pixels;
+        lp = pix - sidx * a.batch_pixels;
+    }
+    const uint32_t ly = lp / (uint32_t)a.frame.width;
+    x = (int)(lp - ly * (uint32_t)a.frame.width);
+    y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
+}
+
 // The key of the sample streams of the Shade() call a frame stands for (recipe S): level 0 frames
 // carry their pixel in fb.w, deeper frames their key.
 template <int TEX>
@@ -157,10 +173,10 @@ __device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) 
     if (smp.on) {
         const uint32_t w = __float_as_uint(fbw);
         if (L == 0) {
-            const uint32_t W = (uint32_t)a.frame.width;
-            const uint32_t ly = w / W, x = w - ly * W;
-            const uint32_t y = ((ly / RTU_BAND_ROWS) * (uint32_t)a.frame.shard_count + (uint32_t)a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS;
-            smp.key = sample_key(x + W * y, a.sample_index);
+            int x, y;
+            uint32_t sidx;
+            pixel_of<TEX>(a, w, x, y, sidx);
+            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index + sidx);
         } else {
             smp.key = w;
         }
@@ -216,7 +232,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
 
 // ---- the primary ray of one pixel -------------------------------------------------------
 template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
-__device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t pix, uint32_t shard,
+__device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t sidx, uint32_t pix, uint32_t shard,
                                               uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
                                               const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
@@ -235,9 +251,9 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         float ox = 0.5f, oy = 0.5f;  // recipe W: the pixel centre
         if (smp.on) {
             // recipe S: RenderFunctions.cpp:80-97 — Halton offsets, a point of the lens disk
-            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index);
-            ox = a.pix_off_x;
-            oy = a.pix_off_y;
+            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index + sidx);
+            ox = a.pix_off_x[sidx];
+            oy = a.pix_off_y[sidx];
             const float sampleX = (float)rand31(smp.key, RTU_DRAW_LENS) / RTU_RAND_MAX_F;          // :88
             const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LENS + 1u) / RTU_THETA_DIV;  // :89
             float sn, cs;
@@ -291,7 +307,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
             lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
-            // list entries of a frame beyond the capacity are harmless: the frame is rendered again
+            // (level 0 is sized for every tile of the launch, ensure_levels: fl < cap_s always holds)
             if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
             if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
         } else {
@@ -307,19 +323,21 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
     uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;  // whole wavefront
+    const uint32_t btile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (btile >= n_tiles) return;  // whole wavefront
+    const uint32_t sidx = SMPD ? btile / a.tiles_per_image : 0u;  // sampled launches: n_tiles = batch x tiles of the image
+    const uint32_t tile = btile - sidx * a.tiles_per_image;
     const uint32_t band_local = tile / a.tiles_x;
     const uint32_t tx = tile - band_local * a.tiles_x;
     const int x = (int)(tx * 8 + (lane & 7));
     const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
     const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
     const bool valid = x < a.frame.width && y < a.frame.height;
-    const uint32_t pix = (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
-    const uint32_t shard = tile % RTU_SHARDS;
+    const uint32_t pix = (SMPD ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+    const uint32_t shard = btile % RTU_SHARDS;
     Counters cnt = {};
     bool deferred;
-    primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, pix, shard, stk, cnt, deferred);
+    primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
     if (!STATS) defer_push(a, 0, shard, deferred, pix);
     flush_counters<STATS>(a, cnt);
 }
@@ -354,11 +372,11 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
         const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        const uint32_t ly = pix / (uint32_t)a.frame.width;
-        const int x = (int)(pix - ly * (uint32_t)a.frame.width);
-        const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
+        int x, y;
+        uint32_t sidx;
+        pixel_of<TEX>(a, pix, x, y, sidx);
         bool deferred;
-        primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, pix, shard, s_stack + lane, cnt, deferred);
+        primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + lane, cnt, deferred);
     }
 }
 
@@ -390,11 +408,11 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
         const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        const uint32_t ly = pix / (uint32_t)a.frame.width;
-        const int x = (int)(pix - ly * (uint32_t)a.frame.width);
-        const int y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
+        int x, y;
+        uint32_t sidx;
+        pixel_of<TEX>(a, pix, x, y, sidx);
         bool deferred;
-        primary_pixel<RTU_STACK8, false, false, true, TEX>(a, valid, x, y, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
+        primary_pixel<RTU_STACK8, false, false, true, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
     }
 }
 
@@ -1088,15 +1106,17 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
 
 // ---- recipe S: the sums of RenderFunctions.cpp:109-110,148 in sample order, and :152 -----------
 namespace {
-__global__ void __launch_bounds__(256) k_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, int first) {
+__global__ void __launch_bounds__(256) k_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, int first) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= pixels) return;
-    const float4 v = sample[i];
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t n = 0;
     if (!first) { s = acc[i]; n = hits[i]; }
-    s.x += v.x; s.y += v.y; s.z += v.z;                // pixelValuesSum += currentResult
-    if (v.w != RTU_BIGFLOAT) { s.w += v.w; n++; }      // zSum += z; numOfHits++
+    for (uint32_t b = 0; b < batch; b++) {  // the samples of the batch in their order
+        const float4 v = samples[(size_t)b * pixels + i];
+        s.x += v.x; s.y += v.y; s.z += v.z;                // pixelValuesSum += currentResult
+        if (v.w != RTU_BIGFLOAT) { s.w += v.w; n++; }      // zSum += z; numOfHits++
+    }
     acc[i] = s;
     hits[i] = n;
 }
@@ -1110,8 +1130,8 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* acc, const uint32
 }
 }  // namespace
 
-int rtu_launch_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream) {
-    hipLaunchKernelGGL(k_accumulate, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, sample, acc, hits, pixels, first ? 1 : 0);
+int rtu_launch_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream) {
+    hipLaunchKernelGGL(k_accumulate, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, samples, batch, acc, hits, pixels, first ? 1 : 0);
     return (int)hipGetLastError();
 }
 int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples, hipStream_t stream) {

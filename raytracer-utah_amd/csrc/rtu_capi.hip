@@ -41,6 +41,8 @@ struct RtuContext {
     float4*   acc = nullptr;             // recipe S accumulators: rgb sum + z sum, hit count
     uint32_t* acc_hits = nullptr;
     size_t    acc_pixels = 0;
+    float4*   sample_buf = nullptr;      // the images of one batch of samples, [sample][pixel]
+    size_t    sample_buf_pixels = 0;
     // k_tail: the recursion level from which the previous frame of this scene was almost empty (a hint —
     // any value renders the same image); last_tail_from: what the most recent frame was launched with
     int      tail_hint = RTU_MAX_LEVELS, last_tail_from = RTU_MAX_LEVELS;
@@ -524,13 +526,14 @@ int alloc_level(RtuContext* ctx, T** dst, size_t count) {
 // pixel; a deeper level starts with the same capacity and is grown to what an overflowed frame
 // reported (check_overflow) — a frame can hold up to 3^L frames per pixel at level L in theory,
 // a tenth of a frame per pixel in the reference's scenes.
-int ensure_levels(RtuContext* ctx, uint32_t pixels) {
-    // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile
-    size_t tiles = ((size_t)pixels + 63) / 64 + 8;  // +8: ragged right/bottom tiles
+int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles) {
+    // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile of the launch (ragged right /
+    // bottom tiles included), so level 0 cannot overflow
+    size_t tiles = n_tiles;
     size_t cap_s0 = ((tiles + RTU_SHARDS - 1) / RTU_SHARDS) * 64;
     size_t want[RTU_MAX_LEVELS];
     size_t maxcap = cap_s0;
-    bool fits = ctx->level_cap0 >= pixels && ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv);
+    bool fits = ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv);
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         want[L] = L == 0 || ctx->want_cap_s[L] < cap_s0 ? cap_s0 : ctx->want_cap_s[L];
         if (want[L] > maxcap) maxcap = want[L];
@@ -584,13 +587,14 @@ float halton(int index, int base) {
     return r;
 }
 
-// One launch sequence: the whole frame of recipe W, or sample `sample_index` of recipe S.
-int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0) {
+// One launch sequence: the whole frame of recipe W, or samples [sample_index, sample_index + batch) of
+// recipe S into d_out as [sample][pixel of the shard].
+int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0, int batch = 1) {
     uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
     uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
-    uint32_t n_tiles = tiles_x * bands;
+    uint32_t n_tiles = tiles_x * bands * (uint32_t)batch;
     uint32_t pixels = (uint32_t)rtu_shard_rows(frame) * (uint32_t)frame->width;
-    int rc = ensure_levels(ctx, pixels);
+    int rc = ensure_levels(ctx, pixels * (uint32_t)batch, n_tiles);
     if (rc != RTU_OK) return rc;
     bool stats = frame->collect_stats != 0;
     if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
@@ -612,12 +616,18 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.n_meshes = ctx->n_meshes;
     a.tail_from = stats ? RTU_MAX_LEVELS : ctx->tail_hint;
     if (frame->samples >= 1) {
-        const float pixelIncrement = (float)(1.0 / frame->samples);         // RenderFunctions.cpp:68
-        const float currentOffset = (float)sample_index * pixelIncrement;  // :80
+        const float pixelIncrement = (float)(1.0 / frame->samples);  // RenderFunctions.cpp:68
         a.sampling = 1;
         a.sample_index = (uint32_t)sample_index;
-        a.pix_off_x = currentOffset + halton(sample_index, 4);              // :84, :96
-        a.pix_off_y = currentOffset + halton(sample_index, 5);              // :85, :96
+        a.batch = (uint32_t)batch;
+        a.batch_pixels = pixels;
+        a.tiles_per_image = tiles_x * bands;
+        for (int b = 0; b < batch; b++) {
+            const int index = sample_index + b;
+            const float currentOffset = (float)index * pixelIncrement;  // :80
+            a.pix_off_x[b] = currentOffset + halton(index, 4);          // :84, :96
+            a.pix_off_y[b] = currentOffset + halton(index, 5);          // :85, :96
+        }
     }
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats;
@@ -682,11 +692,16 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     return RTU_OK;
 }
 
-// Recipe S: one launch sequence per sample, each checked for frame-capacity overflow before its image
-// (in d_out) is added to the accumulators; the mean goes back to d_out. Synchronises per sample.
+// Recipe S: one launch sequence per batch of samples (as many as fit 2^24 pixels, at most RTU_MAX_BATCH),
+// each checked for frame-capacity overflow before its images are added to the accumulators in sample
+// order; the mean goes to d_out. Synchronises per batch.
 int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
     const size_t pixels = (size_t)rtu_shard_rows(frame) * (size_t)frame->width;
     if (pixels == 0) return RTU_OK;
+    int batch = (int)(((size_t)1 << 24) / pixels);
+    if (batch > RTU_MAX_BATCH) batch = RTU_MAX_BATCH;
+    if (batch > frame->samples) batch = frame->samples;
+    if (batch < 1) batch = 1;
     if (pixels > ctx->acc_pixels) {
         if (ctx->acc) (void)hipFree(ctx->acc);
         if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);
@@ -697,10 +712,19 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
         RTU_HIP(ctx, hipMalloc((void**)&ctx->acc_hits, pixels * sizeof(uint32_t)));
         ctx->acc_pixels = pixels;
     }
+    if (pixels * (size_t)batch > ctx->sample_buf_pixels) {
+        if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
+        ctx->sample_buf = nullptr;
+        ctx->sample_buf_pixels = 0;
+        RTU_HIP(ctx, hipMalloc((void**)&ctx->sample_buf, pixels * (size_t)batch * sizeof(float4)));
+        ctx->sample_buf_pixels = pixels * (size_t)batch;
+    }
     int rounds = 0;
-    for (int i = 0; i < frame->samples; i++) {
+    for (int i = 0; i < frame->samples; i += batch) {
+        int nb;
         for (;;) {
-            int rc = launch(ctx, frame, d_out, stream, zero_counters && i == 0, i);
+            nb = frame->samples - i < batch ? frame->samples - i : batch;
+            int rc = launch(ctx, frame, ctx->sample_buf, stream, zero_counters && i == 0, i, nb);
             if (rc != RTU_OK) return rc;
             RTU_HIP(ctx, hipStreamSynchronize(stream));
             bool overflow = false;
@@ -709,7 +733,7 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
             if (++rounds > 4 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
             if (frame->collect_stats) { i = 0; zero_counters = true; }  // the counters of the dropped pass are in the totals: start again
         }
-        hipError_t e = (hipError_t)rtu_launch_accumulate(d_out, ctx->acc, ctx->acc_hits, (uint32_t)pixels, i == 0, stream);
+        hipError_t e = (hipError_t)rtu_launch_accumulate(ctx->sample_buf, (uint32_t)nb, ctx->acc, ctx->acc_hits, (uint32_t)pixels, i == 0, stream);
         if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     }
     hipError_t e = (hipError_t)rtu_launch_resolve(ctx->acc, ctx->acc_hits, d_out, (uint32_t)pixels, (uint32_t)frame->samples, stream);
@@ -776,6 +800,7 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);
+    if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

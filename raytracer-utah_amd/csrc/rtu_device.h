@@ -104,6 +104,7 @@ struct DevScene {
 // children become frames of level L+1, and results are combined bottom-up in the
 // reference's exact term order.
 #define RTU_MAX_LEVELS        (RTU_MAX_BOUNCE + 1)
+#define RTU_MAX_BATCH 16          // samples of recipe S rendered by one launch sequence
 #define RTU_MAX_SHADOW_LIGHTS 13  // non-ambient lights (a ray id keeps 4 bits for lights + 3 secondary slots); more => RTU_ERR_UNSUPPORTED
 
 // frame info word (fa.w)
@@ -183,9 +184,11 @@ struct KernelArgs {
     uint32_t     n_meshes;
     int32_t      tail_from;         // recursion levels >= this are evaluated by k_tail (RTU_MAX_LEVELS: none)
     // recipe S (frame.samples >= 1): one launch sequence per sample
+    // `batch` consecutive samples at once, as [sample][pixel of the shard] (longer ray lists fill the chip better)
     uint32_t     sampling;          // 0: recipe W
-    uint32_t     sample_index;
-    float        pix_off_x, pix_off_y;  // currentOffset + Halton(index, 4 | 5), RenderFunctions.cpp:80-85,96
+    uint32_t     sample_index;      // first sample of the batch
+    uint32_t     batch, batch_pixels, tiles_per_image;
+    float        pix_off_x[RTU_MAX_BATCH], pix_off_y[RTU_MAX_BATCH];  // currentOffset + Halton(index, 4 | 5), RenderFunctions.cpp:80-85,96
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine
@@ -193,7 +196,7 @@ struct KernelArgs {
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
 
 // recipe S: add one sample's image to the accumulators / write the mean
-int rtu_launch_accumulate(const float4* sample, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream);
+int rtu_launch_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream);
 int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples, hipStream_t stream);
 
 int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);

@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline leg (CPU share of one GPU)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
+    ap.add_argument("--frames-in-flight", type=int, default=-1,
+                    help="frames rendered by one launch sequence (rtu_render_frames_device). Default: as many as keep 2^24 pixels in "
+                         "flight on a GPU, at most 16 (8 at 1080p on one GPU, 16 on a shard of 1/2 or less). 1: one frame per launch "
+                         "sequence — the frame LATENCY configuration")
     ap.add_argument("--samples", type=int, default=0,
                     help="diagnostic only: S >= 1 renders recipe S (S samples per pixel; soft shadows, glossy bounces, depth of field) — "
                          "needed for the tags under tests/golden/ whose meta.json says recipe S; not the headline workload")
@@ -99,12 +103,19 @@ def main():
     frame.coop_threshold = args.coop_threshold
     rows = pkg.shard_rows(frame)
     max_rows = pkg.hip.rtu_shard_max_rows(H, world)
-    # two shard / gather buffers: the RCCL gather of frame i runs while frame i+1 is rendered
-    shards = [torch.zeros(max_rows * W * 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    # frames in flight: B frames per launch sequence, as [frame][row of the shard][x] in one buffer
+    B = args.frames_in_flight
+    if args.samples:
+        B = 1  # recipe S batches its samples itself
+    elif B < 1:
+        B = max(1, min(16, (1 << 24) // max(1, max_rows * W)))
+    B = max(1, min(B, 16, args.steps))
+    # two shard / gather buffers: the RCCL gather of batch i runs while batch i+1 is rendered
+    shards = [torch.zeros(B * max_rows * W * 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     root_only = not args.allgather
     gathers = None
     if world > 1 and (rank == 0 or not root_only):
-        gathers = [torch.empty(world, max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
+        gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
     shard = shards[0]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -124,27 +135,32 @@ def main():
 
     pipe = sharding.FramePipeline(shards, gathers, dist, staged=args.rehearse, root_only=root_only) if dist else None
 
-    def step(i, ev=None):
+    def step(i, nb, ev=None):
+        """One launch sequence: nb frames (steps) in flight."""
         buf = pipe.begin(i) if pipe else shard  # waits (on the GPU) for the gather that last read this buffer
         if ev:
             ev[0].record()
-        ctx.render_device(frame, buf.data_ptr(), stream)
+        if nb == 1:
+            ctx.render_device(frame, buf.data_ptr(), stream)
+        else:
+            ctx.render_frames_device([frame] * nb, buf.data_ptr(), stream)
         if ev:
             ev[1].record()
         if pipe:
-            pipe.gather(i)  # RCCL over xGMI, asynchronous: overlaps the next frame's kernels
+            pipe.gather(i)  # RCCL over xGMI, asynchronous: overlaps the next batch's kernels
 
-    for i in range(args.warmup):
-        step(i)
+    for j, i in enumerate(range(0, args.warmup, B)):
+        step(j, min(B, args.warmup - i))
     if pipe:
         pipe.drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    batches = [min(B, args.steps - i) for i in range(0, args.steps, B)]  # EXACTLY args.steps frames
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
+    for j, nb in enumerate(batches):
+        step(j, nb, events[j])
     if pipe:
         pipe.drain()  # every frame of the timed region rendered AND gathered
     torch.cuda.synchronize()
@@ -152,7 +168,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gathered = pipe.last_gathered() if pipe else None
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))  # HIP events on the launch stream
+    # HIP events on the launch stream, around the full launch sequences (B frames each; a shorter last batch is left out)
+    full = [(a.elapsed_time(b), nb) for (a, b), nb in zip(events, batches) if nb == batches[0]]
+    kernel_ms = float(np.mean([t for t, _ in full]))
+    alg_bytes_launch *= batches[0]  # bytes of one launch sequence = frames in flight x bytes of a frame
     ctx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
 
     t = torch.tensor([elapsed, kernel_ms, float(alg_bytes_launch)], dtype=torch.float64, device=cdev)
@@ -170,9 +189,19 @@ def main():
     img = None
     if dist:
         if rank == 0:
-            img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).cpu().numpy(), scene.desc.camera, W, H, world)
+            # the last frame of the last batch: frame j of rank r's chunk starts at j * rows_r * W float4
+            j = batches[-1] - 1
+            chunks = gathered.view(world, -1).cpu().numpy()
+            parts = []
+            for r in range(world):
+                rows_r = pkg.shard_rows(pkg.frame_setup(scene.desc.camera, W, H, shard_rank=r, shard_count=world))
+                part = np.zeros((max_rows, W, 4), np.float32)
+                part[:rows_r] = chunks[r][j * rows_r * W * 4:(j + 1) * rows_r * W * 4].reshape(rows_r, W, 4)
+                parts.append(part)
+            img = sharding.assemble_gathered(pkg, np.stack(parts), scene.desc.camera, W, H, world)
     else:
-        img = shard.view(max_rows, W, 4)[:H].cpu().numpy()
+        j = batches[-1] - 1
+        img = shard.view(-1)[j * rows * W * 4:(j + 1) * rows * W * 4].view(rows, W, 4).cpu().numpy()
     if args.rehearse and rank == 0:
         print("[rehearsal: %d ranks on one GPU through gloo — not a measurement]" % world, file=sys.stderr)
     import hashlib
@@ -185,7 +214,7 @@ def main():
         traffic = None
         tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if world == 1 and args.tag == WORKLOAD_TAG and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("bytes_per_launch")
+            traffic = json.load(open(tfile)).get("bytes_per_launch_by_frames_in_flight", {}).get(str(batches[0]))
         out = {
             "metric": "Mrays/sec at 1920x1080 (primary + secondary + shadow rays per frame / frame time)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,6 +224,7 @@ def main():
                        "width": W, "height": H,
                        "rays_per_frame": rays_per_frame, "primary": total["primary_rays"],
                        "secondary": total["secondary_rays"], "shadow": total["shadow_rays"],
+                       "frames_in_flight": batches[0], "frame_latency_ms": round(kernel_ms, 4),
                        "sharding": "interleaved 8-row bands, RCCL gather of the float4 framebuffer to rank 0, overlapped with the next frame" if world > 1 else "single GPU",
                        "z_bit_exact_vs_reference_golden": bool(z_ok)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -44,6 +44,9 @@ namespace {
 // bounces, lens). Recipe W on an untextured scene compiles to exactly the code it had before either existed.
 #define TEXD ((TEX & 1) != 0)
 #define SMPD ((TEX & 2) != 0)
+// bit 2: the launch renders a batch of FRAMES of recipe W (rtu_render_frames_device), each with its own
+// camera; its pixel index space is [frame in batch][pixel of the shard], like a batch of samples
+#define BATD ((TEX & 4) != 0)
 
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
 // k_trace slot selection bits
@@ -154,7 +157,7 @@ template <int TEX>
 __device__ __forceinline__ void pixel_of(const KernelArgs& a, uint32_t pix, int& x, int& y, uint32_t& sidx) {
     sidx = 0;
     uint32_t lp = pix;
-    if (SMPD) {
+    if (SMPD || BATD) {
         sidx = pix / a.batch_pixels;
         lp = pix - sidx * a.batch_pixels;
     }
@@ -240,7 +243,15 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     Hit h;
     fresh_hit(h, RTU_BIGFLOAT);
     Ray ray;
+    f3 cam_origin = ld3(a.frame.origin), cam_u = ld3(a.frame.u), cam_v = ld3(a.frame.v);
     ray.p = ld3(a.frame.cam_pos);
+    if (BATD) {  // every frame of the batch has its own camera
+        const BatchCam& c = a.cam[sidx];
+        ray.p = ld3(c.pos);
+        cam_origin = ld3(c.origin);
+        cam_u = ld3(c.u);
+        cam_v = ld3(c.v);
+    }
     ray.dir = mk3(0, 0, 0);
     int mid = -1;
     deferred = false;
@@ -263,7 +274,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             ray.p = (ray.p + ld3(a.frame.lens_up) * camOffsetY) + ld3(a.frame.lens_right) * camOffsetX;  // :93
         }
         // RenderFunctions.cpp:258-268, :97
-        f3 cp = (ld3(a.frame.origin) + ld3(a.frame.u) * ((float)x + ox)) + ld3(a.frame.v) * ((float)y + oy);
+        f3 cp = (cam_origin + cam_u * ((float)x + ox)) + cam_v * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
         bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
@@ -325,7 +336,7 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t btile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (btile >= n_tiles) return;  // whole wavefront
-    const uint32_t sidx = SMPD ? btile / a.tiles_per_image : 0u;  // sampled launches: n_tiles = batch x tiles of the image
+    const uint32_t sidx = (SMPD || BATD) ? btile / a.tiles_per_image : 0u;  // batched launches: n_tiles = batch x tiles of the image
     const uint32_t tile = btile - sidx * a.tiles_per_image;
     const uint32_t band_local = tile / a.tiles_x;
     const uint32_t tx = tile - band_local * a.tiles_x;
@@ -333,7 +344,7 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
     const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
     const bool valid = x < a.frame.width && y < a.frame.height;
-    const uint32_t pix = (SMPD ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+    const uint32_t pix = ((SMPD || BATD) ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
     const uint32_t shard = btile % RTU_SHARDS;
     Counters cnt = {};
     bool deferred;
@@ -648,7 +659,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     const bool haveNext = L + 1 < RTU_MAX_LEVELS;
     const int Ln = haveNext ? L + 1 : L;
     const LevelBuffers& nx = a.lv[Ln];
-    const f3 cam_pos = ld3(a.frame.cam_pos);
+    f3 cam_pos = ld3(a.frame.cam_pos);
     st_out[0] = st_out[1] = st_out[2] = RTU_CH_NONE;
     float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
     if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
@@ -657,6 +668,13 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
     const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
     const Smp smp = frame_smp<TEX>(a, L, fb.w);
+    uint32_t entry = 0;  // batched frames: which frame of the batch this Shade() belongs to (its camera, :137)
+    if (BATD) {
+        entry = __float_as_uint(fb.w);
+        if (L == 0) entry /= a.batch_pixels;
+        if (entry >= a.batch) entry = 0;  // inactive lanes
+        cam_pos = ld3(a.cam[entry].pos);
+    }
     f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
     if (TEXD && active) {
         const float4 t = lv.fuv[f];
@@ -771,7 +789,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
             }
             const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp);
             nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(csmp.key));
+            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(BATD ? entry : csmp.key));
             nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
             st[k] = (int)idx;
             wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
@@ -1160,10 +1178,12 @@ static int launch_feat(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_st
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
     // textured scenes and sampled frames run their own instantiations: the others carry no uvw, sample
     // nothing and draw nothing
-    switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : 0)) {
+    switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0))) {
         case 0: return launch_feat<0>(args, n_tiles, bvh_stack_needed, stats, stream);
         case 1: return launch_feat<1>(args, n_tiles, bvh_stack_needed, stats, stream);
         case 2: return launch_feat<2>(args, n_tiles, bvh_stack_needed, stats, stream);
-        default: return launch_feat<3>(args, n_tiles, bvh_stack_needed, stats, stream);
+        case 3: return launch_feat<3>(args, n_tiles, bvh_stack_needed, stats, stream);
+        case 4: return launch_feat<4>(args, n_tiles, bvh_stack_needed, stats, stream);
+        default: return launch_feat<5>(args, n_tiles, bvh_stack_needed, stats, stream);
     }
 }

@@ -589,7 +589,9 @@ float halton(int index, int base) {
 
 // One launch sequence: the whole frame of recipe W, or samples [sample_index, sample_index + batch) of
 // recipe S into d_out as [sample][pixel of the shard].
-int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0, int batch = 1) {
+// frames_batch: `batch` frames of recipe W with their own cameras (frame == &frames_batch[0]).
+int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0, int batch = 1,
+           const RtuFrameDesc* frames_batch = nullptr) {
     uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
     uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
     uint32_t n_tiles = tiles_x * bands * (uint32_t)batch;
@@ -627,6 +629,18 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
             const float currentOffset = (float)index * pixelIncrement;  // :80
             a.pix_off_x[b] = currentOffset + halton(index, 4);          // :84, :96
             a.pix_off_y[b] = currentOffset + halton(index, 5);          // :85, :96
+        }
+    }
+    if (frames_batch) {
+        a.frame_batch = 1;
+        a.batch = (uint32_t)batch;
+        a.batch_pixels = pixels;
+        a.tiles_per_image = tiles_x * bands;
+        for (int b = 0; b < batch; b++) {
+            memcpy(a.cam[b].pos, frames_batch[b].cam_pos, sizeof a.cam[b].pos);
+            memcpy(a.cam[b].origin, frames_batch[b].origin, sizeof a.cam[b].origin);
+            memcpy(a.cam[b].u, frames_batch[b].u, sizeof a.cam[b].u);
+            memcpy(a.cam[b].v, frames_batch[b].v, sizeof a.cam[b].v);
         }
     }
     ctx->last_tail_from = a.tail_from;
@@ -1058,6 +1072,28 @@ int rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_
     hipStream_t st = (hipStream_t)hip_stream;  // NULL is the device's default (null) stream
     if (frame->samples >= 1) return render_sampled(ctx, frame, (float4*)d_rgbz, st, true);
     return launch(ctx, frame, (float4*)d_rgbz, st, true);
+}
+
+int rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_frames, void* d_rgbz, void* hip_stream) {
+    if (!ctx) return RTU_ERR_ARG;
+    if (!frames || n_frames < 1 || n_frames > RTU_MAX_FRAMES_IN_FLIGHT) return fail(ctx, RTU_ERR_ARG, "1..%d frames per call", RTU_MAX_FRAMES_IN_FLIGHT);
+    for (int i = 0; i < n_frames; i++) {
+        int rc = check_frame(ctx, &frames[i]);
+        if (rc != RTU_OK) return rc;
+        const RtuFrameDesc &f = frames[i], &g = frames[0];
+        if (f.samples != 0) return fail(ctx, RTU_ERR_ARG, "frames in flight are frames of recipe W (samples == 0)");
+        if (f.width != g.width || f.height != g.height || f.shard_rank != g.shard_rank || f.shard_count != g.shard_count ||
+            f.max_bounce != g.max_bounce || f.collect_stats != g.collect_stats || f.coop_threshold != g.coop_threshold)
+            return fail(ctx, RTU_ERR_ARG, "frames in flight differ in more than their cameras");
+    }
+    if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
+    const size_t pixels = (size_t)rtu_shard_rows(&frames[0]) * (size_t)frames[0].width;
+    if (pixels == 0) return RTU_OK;
+    if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
+    if (pixels * (size_t)n_frames > ((size_t)1 << 26)) return fail(ctx, RTU_ERR_ARG, "more than 2^26 pixels in flight");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    static_assert(RTU_MAX_FRAMES_IN_FLIGHT == RTU_MAX_BATCH, "batch size");
+    return launch(ctx, &frames[0], (float4*)d_rgbz, (hipStream_t)hip_stream, true, 0, n_frames, frames);
 }
 
 int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {

@@ -167,6 +167,10 @@ struct FrameCounters {
     uint32_t pad[3];
 };
 
+struct BatchCam {
+    float pos[3], origin[3], u[3], v[3];  // RtuFrameDesc cam_pos / origin / u / v
+};
+
 struct KernelArgs {
     DevScene     scene;
     RtuFrameDesc frame;
@@ -189,6 +193,9 @@ struct KernelArgs {
     uint32_t     sample_index;      // first sample of the batch
     uint32_t     batch, batch_pixels, tiles_per_image;
     float        pix_off_x[RTU_MAX_BATCH], pix_off_y[RTU_MAX_BATCH];  // currentOffset + Halton(index, 4 | 5), RenderFunctions.cpp:80-85,96
+    // a batch of FRAMES of recipe W (rtu_render_frames_device): the same index space, one camera per frame
+    uint32_t     frame_batch;       // 0: no
+    BatchCam     cam[RTU_MAX_BATCH];
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine

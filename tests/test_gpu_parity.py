@@ -524,3 +524,61 @@ def test_errors_are_codes_not_crashes(pkg, ctx, golden):
     err = ctypes.c_int(0)
     assert not pkg.hip.rtu_create_context(9999, ctypes.byref(err))
     assert err.value == pkg.RTU_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("tag,shards", [("teapot2_240x135", 1), ("p4_240x135", 1), ("p7_200x150", 1), ("p11_240x135", 3)])
+def test_frames_in_flight_equal_single_frames(pkg, ctx, golden, tag, shards):
+    """rtu_render_frames_device: a batch of frames with different cameras rendered by one launch sequence —
+    every image equals the one rtu_render_frame gives for that frame alone, bit for bit (fast and counting
+    variants; sharded; textured), and a frame with the golden's camera still has the golden's z."""
+    import copy
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    n = 5
+    for rank in range(shards):
+        frames = []
+        for i in range(n):
+            cam = copy.copy(scene.desc.camera)
+            cam = type(cam).from_buffer_copy(bytes(cam))
+            cam.pos[0] += 0.37 * i
+            cam.pos[2] += 0.11 * i * i
+            cam.fov += 1.5 * i
+            frames.append(pkg.frame_setup(cam, W, H, shard_rank=rank, shard_count=shards))
+        rows = pkg.shard_rows(frames[0])
+        singles = [ctx.render(f)[0] for f in frames]
+        assert not np.array_equal(singles[0], singles[1])
+        d = pkg.hip.rtu_device_alloc(ctx._h, n * rows * W * 16)
+        for stats in (False, True):
+            for f in frames:
+                f.collect_stats = 1 if stats else 0
+            ctx.render_frames_device(frames, d)
+            ctx.frame_status()
+            got = np.empty((n, rows, W, 4), np.float32)
+            assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+            for i in range(n):
+                assert np.array_equal(got[i].view(np.uint32), singles[i].view(np.uint32)), "frame %d of the batch differs (stats=%s)" % (i, stats)
+        if shards == 1:
+            assert sha256(got[0][..., 3]) == g.meta["sha256_z_f32"]
+        # any tail cut level gives the same images
+        for f in frames:
+            f.collect_stats = 0
+        for level in (1, 3):
+            assert pkg.hip.rtu_debug_tail_from(ctx._h, level) == 0
+            ctx.render_frames_device(frames, d)
+            ctx.frame_status()
+            assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+            assert all(np.array_equal(got[i].view(np.uint32), singles[i].view(np.uint32)) for i in range(n))
+        pkg.hip.rtu_device_free(ctx._h, d)
+    # errors: frames that differ in more than their cameras, too many frames, sampled frames
+    a, b = pkg.frame_setup(scene.desc.camera, W, H), pkg.frame_setup(scene.desc.camera, W, H + 8)
+    d = pkg.hip.rtu_device_alloc(ctx._h, 20 * (H + 8) * W * 16)
+    arr = (pkg.RtuFrameDesc * 2)(a, b)
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG
+    arr17 = (pkg.RtuFrameDesc * 17)(*([a] * 17))
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr17, 17, d, None) == pkg.RTU_ERR_ARG
+    s = pkg.frame_setup(scene.desc.camera, W, H, samples=2)
+    arr = (pkg.RtuFrameDesc * 2)(s, s)
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG
+    pkg.hip.rtu_device_free(ctx._h, d)

@@ -149,8 +149,8 @@ def main():
         if pipe:
             pipe.gather(i)  # RCCL over xGMI, asynchronous: overlaps the next batch's kernels
 
-    for j, i in enumerate(range(0, args.warmup, B)):
-        step(j, min(B, args.warmup - i))
+    for j in range(max(1, -(-args.warmup // B))):
+        step(j, B)  # warm-up at the full batch size (at least args.warmup frames): buffers are provisioned for B frames in flight
     if pipe:
         pipe.drain()
     batches = [min(B, args.steps - i) for i in range(0, args.steps, B)]  # EXACTLY args.steps frames

@@ -228,7 +228,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     g.sum = sum;
     // enough wavefronts to fill 256 CUs several times over before widening them
     // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
-    g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 200000) ? 64u : 8u;
+    g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 120000) ? 64u : 8u;
     g.kmax = (v + g.R - 1u) / g.R;
     return g;
 }

@@ -706,13 +706,13 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     return RTU_OK;
 }
 
-// Recipe S: one launch sequence per batch of samples (as many as fit 2^24 pixels, at most RTU_MAX_BATCH),
+// Recipe S: one launch sequence per batch of samples (as many as fit 2^25 pixels, at most RTU_MAX_BATCH),
 // each checked for frame-capacity overflow before its images are added to the accumulators in sample
 // order; the mean goes to d_out. Synchronises per batch.
 int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
     const size_t pixels = (size_t)rtu_shard_rows(frame) * (size_t)frame->width;
     if (pixels == 0) return RTU_OK;
-    int batch = (int)(((size_t)1 << 24) / pixels);
+    int batch = (int)(((size_t)1 << 25) / pixels);
     if (batch > RTU_MAX_BATCH) batch = RTU_MAX_BATCH;
     if (batch > frame->samples) batch = frame->samples;
     if (batch < 1) batch = 1;

@@ -7,19 +7,24 @@
                            frame's kernels), read by bench.py into roofline.traffic
 """
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
+def newest(pattern):
+    """gpurun merges a run's files into what is already under gpurun_out/: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = "gpurun_out/round"
 os.makedirs("profiles", exist_ok=True)
-st = glob.glob(root + "/stats/*/*_kernel_stats.csv")[0]
+st = newest(root + "/stats/*/*_kernel_stats.csv")
 shutil.copyfile(st, "profiles/%s_kernel_stats.csv" % tag)
-tl = subprocess.run([sys.executable, "tools/frame_timeline.py", root + "/stats/*/*_kernel_trace.csv"], capture_output=True, text=True).stdout
+tl = subprocess.run([sys.executable, "tools/frame_timeline.py", newest(root + "/stats/*/*_kernel_trace.csv")], capture_output=True, text=True).stdout
 open("profiles/%s_frame_timeline.txt" % tag, "w").write(tl)
 pm = subprocess.run([sys.executable, "tools/pmc_summary.py", root + "/pmc_*/*/*_counter_collection.csv"], capture_output=True, text=True).stdout
 open("profiles/%s_pmc_per_kernel.txt" % tag, "w").write(pm)
 
 def per_frame(counter, d, root=root):
     """Mean counter sum per launch sequence (k_primary .. last k_combine) of the fast kernel variant."""
-    f = glob.glob(root + "/%s/*/*_counter_collection.csv" % d)[0]
+    f = newest(root + "/%s/*/*_counter_collection.csv" % d)
     per = collections.defaultdict(float)
     names = {}
     for r in csv.DictReader(open(f)):
@@ -50,7 +55,7 @@ def fif_of(root):
 by_fif = {str(fif_of(root)): int((fetch_kb + write_kb) * 1024)}
 for extra in sorted(glob.glob("gpurun_out/round_fif*")):
     by_fif[str(fif_of(extra))] = int((per_frame("FETCH_SIZE", "pmc_fetch", extra) + per_frame("WRITE_SIZE", "pmc_write", extra)) * 1024)
-    st2 = glob.glob(extra + "/stats/*/*_kernel_stats.csv")[0]
+    st2 = newest(extra + "/stats/*/*_kernel_stats.csv")
     shutil.copyfile(st2, "profiles/%s_%s_kernel_stats.csv" % (tag, os.path.basename(extra).replace("round_", "")))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --steps 48 --warmup 16 --no-cpu [--frames-in-flight n]",
        "fetch_size_kb_per_launch_sequence": fetch_kb, "write_size_kb_per_launch_sequence": write_kb,

@@ -189,16 +189,8 @@ def main():
     img = None
     if dist:
         if rank == 0:
-            # the last frame of the last batch: frame j of rank r's chunk starts at j * rows_r * W float4
-            j = batches[-1] - 1
-            chunks = gathered.view(world, -1).cpu().numpy()
-            parts = []
-            for r in range(world):
-                rows_r = pkg.shard_rows(pkg.frame_setup(scene.desc.camera, W, H, shard_rank=r, shard_count=world))
-                part = np.zeros((max_rows, W, 4), np.float32)
-                part[:rows_r] = chunks[r][j * rows_r * W * 4:(j + 1) * rows_r * W * 4].reshape(rows_r, W, 4)
-                parts.append(part)
-            img = sharding.assemble_gathered(pkg, np.stack(parts), scene.desc.camera, W, H, world)
+            # the last frame of the last batch (frame j of rank r's chunk starts at j * rows_r * W float4)
+            img = sharding.assemble_gathered_batch(pkg, gathered.view(world, -1).cpu().numpy(), batches[-1] - 1, scene.desc.camera, W, H, world)
     else:
         j = batches[-1] - 1
         img = shard.view(-1)[j * rows * W * 4:(j + 1) * rows * W * 4].view(rows, W, 4).cpu().numpy()

@@ -61,6 +61,20 @@ def assemble_gathered(pkg, gathered_np, camera, width, height, world):
     return pkg.assemble([gathered_np[r] for r in range(world)], frames, height)
 
 
+def assemble_gathered_batch(pkg, chunks_np, j, camera, width, height, world):
+    """Frames in flight: rank r's gathered chunk holds its shard of every frame of the batch, frame j at
+    float offset j * rows_r * W * 4 (rows_r = the rows of rank r's shard, not the padded maximum).
+    chunks_np: [world, >= B * rows_r * W * 4]. Returns frame j as [H, W, 4]."""
+    import numpy as np
+    frames = [pkg.frame_setup(camera, width, height, shard_rank=r, shard_count=world) for r in range(world)]
+    parts = []
+    for r in range(world):
+        rows_r = pkg.shard_rows(frames[r])
+        n = rows_r * width * 4
+        parts.append(np.asarray(chunks_np[r][j * n:(j + 1) * n]).reshape(rows_r, width, 4))
+    return pkg.assemble(parts, frames, height)
+
+
 def global_minmax_z(z_local, dist, torch):
     """z-image normalisation needs the frame-wide zmin/zmax (scene.h:596-601): a 2-float
     all-reduce when the frame is not gathered to one place."""

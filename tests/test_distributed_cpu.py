@@ -62,6 +62,22 @@ def _worker(rank, world, port, tag, out_dir):
             assert torch.equal(gathers[0].view(-1), gathered) and torch.equal(gathers[1].view(-1), gathered)
         else:
             assert pipe.last_gathered() is None
+    # frames in flight (bench.py's default): B shards per rank in one buffer, frame j at j * rows_r * W float4,
+    # one gather per batch; frame 1 of the batch carries a marker so that a wrong offset cannot go unnoticed
+    B = 3
+    n_r = len(rows) * W * 4
+    batch = torch.zeros(B * max_rows * W * 4, dtype=torch.float32)
+    for j in range(B):
+        batch[j * n_r:(j + 1) * n_r] = shard[:n_r] + (1000.0 if j == 1 else 0.0)
+    gb = [torch.empty(world, B * max_rows * W * 4), torch.empty(world, B * max_rows * W * 4)] if rank == 0 else None
+    pipe = sharding.FramePipeline([batch, batch.clone()], gb, dist, root_only=True)
+    pipe.begin(0)
+    pipe.gather(0)
+    pipe.drain()
+    if rank == 0:
+        for j in range(B):
+            fj = sharding.assemble_gathered_batch(pkg, pipe.last_gathered().numpy(), j, scene.desc.camera, W, H, world)
+            np.save(os.path.join(out_dir, "batch%d.npy" % j), fj)
     lo, hi = sharding.global_minmax_z(shard.view(max_rows, W, 4)[:len(rows), :, 3], dist, torch)
     img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).numpy(), scene.desc.camera, W, H, world)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
@@ -83,4 +99,7 @@ def test_sharded_gather_reassembles_the_frame(pkg, orc, golden, tmp_path, world)
         img = np.load(tmp_path / ("rank%d.npy" % r))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "rank %d assembled a different frame" % r
         lo, hi = np.load(tmp_path / ("minmax%d.npy" % r))
+    for j in range(3):
+        fj = np.load(tmp_path / ("batch%d.npy" % j))
+        assert np.array_equal(fj, ref + np.float32(1000.0 if j == 1 else 0.0)), "frame %d of the gathered batch" % j
         assert lo == z[z != np.float32(1e30)].min() and hi == z[z != np.float32(1e30)].max()

@@ -128,8 +128,8 @@ int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d
 /* Frames in flight: n_frames frames of recipe W of the uploaded scene — the same resolution, shard and
  * options, each with its own camera (cam_pos / origin / u / v) — rendered by ONE launch sequence into
  * d_rgbz = n_frames consecutive shard images (frame i at float4 offset i * rtu_shard_rows * width).
- * One 1080p frame at one sample per pixel is too little work to fill 256 CUs: eight in
- * flight render at about twice the rays per second. Every frame is the image rtu_render_frame_device
+ * One 1080p frame at one sample per pixel is too little work to fill 256 CUs: sixteen in
+ * flight render at 2.4 times the rays per second. Every frame is the image rtu_render_frame_device
  * gives for it, bit for bit. Asynchronous; rtu_frame_status afterwards as for a single frame. */
 #define RTU_MAX_FRAMES_IN_FLIGHT 16
 int  rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_frames, void* d_rgbz, void* hip_stream);

@@ -123,3 +123,38 @@ def test_random_scene(pkg, orc, ctx, assets, seed):
         fr.coop_threshold = thr
         fast, _ = ctx.render(fr)
         assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast (threshold %d) and counting variants differ" % thr
+
+
+def _make_stochastic(xml, rnd):
+    """The random scene with the reference's stochastic attributes added: glossy reflection / refraction,
+    point lights with a size, a lens (focal distance at the look-at distance)."""
+    import re
+    xml = re.sub(r'<reflection value="([^"]+)"/>', lambda m: '<reflection value="%s" glossiness="%r"/>' % (m.group(1), rnd.choice([0.0, 0.03, 0.1, 0.3])), xml)
+    xml = re.sub(r'(<refraction index="[^"]+" value="[^"]+")/>', lambda m: '%s glossiness="%r"/>' % (m.group(1), rnd.choice([0.0, 0.02, 0.08])), xml)
+    xml = re.sub(r'(<light type="point" name="p\d+">)', lambda m: m.group(1) + '<size value="%r"/>' % rnd.choice([0.0, 0.5, 2.0, 5.0]), xml)
+    if rnd.random() < 0.6:
+        xml = xml.replace('<fov value=', '<focaldist value="%r"/><dof value="%r"/><fov value=' % (rnd.uniform(10, 20), rnd.uniform(0.05, 0.6)))
+    return xml
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_sampled(pkg, orc, ctx, assets, seed):
+    """Recipe S on random scenes: glossy bounces, soft shadows, depth of field, 1-5 samples per pixel, against
+    the oracle on the keyed sample streams — z bit-exact, RGB within the bar, counters equal, both stage-2 forms."""
+    rnd = random.Random(7000 + seed)
+    textured = seed % 3 == 2
+    xml = assets / ("ss%d.xml" % seed)
+    xml.write_text(_make_stochastic(_scene_xml(rnd, assets, textured), rnd))
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H, spp = 96, 64, 1 + seed % 5
+    cpu, cst = orc.render_samples(scene, W, H, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=4)
+    ctx.upload(scene)
+    frs = pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True, samples=spp)
+    cnt, gst = ctx.render(frs, stats=True)
+    check_against(cnt, cpu, orc, rel_tol=3e-4)
+    assert gst == cst
+    for thr in (10 ** 9, 1):
+        fr = pkg.frame_setup(scene.desc.camera, W, H, samples=spp)
+        fr.coop_threshold = thr
+        fast, _ = ctx.render(fr)
+        assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast (threshold %d) and counting variants differ" % thr

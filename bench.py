@@ -149,10 +149,24 @@ def main():
         if pipe:
             pipe.gather(i)  # RCCL over xGMI, asynchronous: overlaps the next batch's kernels
 
-    for j in range(max(1, -(-args.warmup // B))):
-        step(j, B)  # warm-up at the full batch size (at least args.warmup frames): buffers are provisioned for B frames in flight
-    if pipe:
-        pipe.drain()
+    for attempt in range(2 * 6 + 1):
+        for j in range(max(1, -(-args.warmup // B))):
+            step(j, B)  # warm-up at the full batch size (at least args.warmup frames): buffers are provisioned for B frames in flight
+        if pipe:
+            pipe.drain()
+        settled = 1
+        try:
+            ctx.frame_status()  # a recursion level needed more frame records than provisioned: the context has grown them, warm up again
+        except pkg.RtuError as e:
+            if e.code != pkg.RTU_ERR_CAPACITY or attempt == 2 * 6:
+                raise
+            settled = 0
+        if dist:  # every rank repeats the warm-up (and its gathers) if any rank has to
+            flag = torch.tensor([settled], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            settled = int(flag[0])
+        if settled:
+            break
     batches = [min(B, args.steps - i) for i in range(0, args.steps, B)]  # EXACTLY args.steps frames
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
     if dist:

@@ -1193,6 +1193,7 @@ int rtu_render_timeline(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz
     if (rc != RTU_OK) return rc;
     if (!ctx->has_scene) return fail(ctx, RTU_ERR_NO_SCENE, "no scene uploaded");
     if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
+    if (frame->samples != 0) return fail(ctx, RTU_ERR_ARG, "the timeline is of one launch sequence of recipe W (samples == 0)");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)RTU_TL_KERNELS * RTU_TL_STRIDE;
     if (!ctx->tl) RTU_HIP(ctx, hipMalloc((void**)&ctx->tl, n * sizeof(unsigned long long)));

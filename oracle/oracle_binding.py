@@ -41,6 +41,10 @@ lib.rtu_oracle_postprocess.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_i
 lib.rtu_oracle_render_samples.restype = ctypes.c_int
 lib.rtu_oracle_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OracleStats), ctypes.c_int]
+lib.rtu_oracle_render_paths.restype = ctypes.c_int
+lib.rtu_oracle_render_paths.argtypes = lib.rtu_oracle_render_samples.argtypes
+lib.rtu_oracle_portable_acos.restype = None
+lib.rtu_oracle_portable_acos.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 lib.rtu_oracle_portable_sincos.restype = None
 lib.rtu_oracle_portable_sincos.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 for _n, _k in (("rtu_oracle_rand31", 2), ("rtu_oracle_sample_key", 2), ("rtu_oracle_child_key", 2)):
@@ -79,6 +83,26 @@ def render_samples(scene, width, height, spp, stream=STREAM_KEYED, trig=TRIG_POR
     if rc != 0:
         raise OracleError(rc)
     return out, st.as_dict()
+
+
+def render_paths(scene, width, height, spp, stream=STREAM_KEYED, trig=TRIG_PORTABLE, threads=1, row0=0, nrows=None):
+    """Recipe P (config 5): recipe S plus the 4-bounce Monte-Carlo gather."""
+    if nrows is None:
+        nrows = height - row0
+    out = np.empty((nrows, width, 4), np.float32)
+    st = OracleStats()
+    rc = lib.rtu_oracle_render_paths(scene.desc_ptr, width, height, row0, nrows, spp, stream, trig, out.ctypes.data,
+                                     ctypes.byref(st), threads)
+    if rc != 0:
+        raise OracleError(rc)
+    return out, st.as_dict()
+
+
+def portable_acos(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib.rtu_oracle_portable_acos(x.ctypes.data, x.size, out.ctypes.data)
+    return out
 
 
 def portable_sincos(t):

@@ -376,7 +376,8 @@ extern "C" int __wrap_rand(void) {
     return (int)(mix32(t_key ^ mix32((t_counter++) * 0x9e3779b9U + 0x85ebca6bU)) >> 1);
 }
 
-static void RenderRowsSampled(int y0, int y1, int spp, float* z, float* rgb, std::atomic<long long>* hits) {
+// gi: recipe P — the Monte-Carlo gather of Render() (RenderFunctions.cpp:129-135) before the direct Shade.
+static void RenderRowsSampled(int y0, int y1, int spp, bool gi, float* z, float* rgb, std::atomic<long long>* hits) {
     const int W = camera.imgWidth;
     long long nh = 0;
     float pixelIncrement = 1.0 / spp;
@@ -407,7 +408,14 @@ static void RenderRowsSampled(int y0, int y1, int spp, float* z, float* rgb, std
                     zSum += h.z;
                     numOfHits++;
                     const Material* mtl = h.node->GetMaterial();
-                    c = mtl ? mtl->Shade(ray, h, lights, 5) : Color(1, 1, 1);
+                    if (gi && mtl) {
+                        LightList monteCarloList;
+                        MonteCarlo(monteCarloList, h, x, y, monteCarloBounces, monteCarloSampleSize);
+                        c = mtl->Shade(ray, h, monteCarloList, 5);
+                        c += mtl->Shade(ray, h, lights, 5);
+                    } else {
+                        c = mtl ? mtl->Shade(ray, h, lights, 5) : Color(1, 1, 1);
+                    }
                 } else {
                     c = background.Sample(Point3((float)x / camera.imgWidth, (float)y / camera.imgHeight, 0));
                 }
@@ -439,7 +447,7 @@ static bool WriteFile(const std::string& path, const void* p, size_t n) {
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s scene.xml width height outdir [threads] [--scene-only | --spp N]\n", argv[0]);
+        fprintf(stderr, "usage: %s scene.xml width height outdir [threads] [--scene-only | --spp N | --paths N]\n", argv[0]);
         return 1;
     }
     const char* xml = argv[1];
@@ -447,7 +455,8 @@ int main(int argc, char** argv) {
     std::string out = argv[4];
     int threads = argc > 5 ? atoi(argv[5]) : 1;
     bool sceneOnly = argc > 6 && strcmp(argv[6], "--scene-only") == 0;
-    int spp = (argc > 7 && strcmp(argv[6], "--spp") == 0) ? atoi(argv[7]) : 0;  // 0: recipe W
+    int spp = (argc > 7 && (strcmp(argv[6], "--spp") == 0 || strcmp(argv[6], "--paths") == 0)) ? atoi(argv[7]) : 0;  // 0: recipe W
+    bool gi = argc > 7 && strcmp(argv[6], "--paths") == 0;  // recipe P
     if (threads < 1) threads = 1;
 
     if (!LoadScene(xml)) return 3;
@@ -472,7 +481,7 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) {
         int y0 = (int)((long long)H * t / threads), y1 = (int)((long long)H * (t + 1) / threads);
-        if (spp > 0) th.emplace_back(RenderRowsSampled, y0, y1, spp, z.data(), rgb.data(), &hits);
+        if (spp > 0) th.emplace_back(RenderRowsSampled, y0, y1, spp, gi, z.data(), rgb.data(), &hits);
         else th.emplace_back(RenderRows, y0, y1, org, z.data(), rgb.data(), &hits);
     }
     for (auto& t : th) t.join();
@@ -492,7 +501,7 @@ int main(int argc, char** argv) {
             "\"primary_hits\": %lld, \"secondary\": %lld, \"shadow\": %lld}\n",
             W, H, spp, threads, sec, (long long)W * H * (spp > 0 ? spp : 1), hits.load(), g_secondary.load(), g_shadow.load());
     fclose(fp);
-    printf("recipe %s %dx%d: %.3f s, hits %lld, secondary %lld, shadow %lld\n", spp > 0 ? "S" : "W", W, H, sec, hits.load(),
+    printf("recipe %s %dx%d: %.3f s, hits %lld, secondary %lld, shadow %lld\n", gi ? "P" : spp > 0 ? "S" : "W", W, H, sec, hits.load(),
            g_secondary.load(), g_shadow.load());
     return 0;
 }

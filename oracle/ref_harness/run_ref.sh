@@ -2,11 +2,13 @@
 # run_ref.sh — run the compiled reference (oracle/_ref/ref_render) on one scene.
 # Authoring container only. The reference's XMLs carry the author's absolute
 # macOS paths: a path-remapped COPY is written under oracle/_ref/.
-#   usage: run_ref.sh <scene path relative to SceneFiles> <W> <H> <tag> [threads] [spp]   (spp: recipe S)
+#   usage: run_ref.sh <scene path relative to SceneFiles> <W> <H> <tag> [threads] [spp] [paths]   (spp: recipe S; "paths": recipe P)
 set -e
 REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$HERE/oracle/_ref/out/$4
 mkdir -p "$OUT"
 sed "s#/Users/Peter/GitRepos/RayTracer-Utah#$REF#g" "$REF/SceneFiles/$1" > "$OUT/scene.xml"
-"$HERE/oracle/_ref/ref_render" "$OUT/scene.xml" "$2" "$3" "$OUT" "${5:-8}" ${6:+--spp $6} | tail -1
+MODE=""
+if [ -n "$6" ]; then if [ -n "$7" ]; then MODE="--paths $6"; else MODE="--spp $6"; fi; fi
+"$HERE/oracle/_ref/ref_render" "$OUT/scene.xml" "$2" "$3" "$OUT" "${5:-8}" $MODE | tail -1

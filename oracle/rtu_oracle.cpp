@@ -98,6 +98,7 @@ struct Ctx {
     bool sequential;     // true: the n-th rand() call of a pixel sample (pins the restatement against the reference)
     bool libm_trig;      // true: cosf/sinf of libm as the reference calls them; false: the portable sincos the device uses
     uint32_t seq_key, seq_counter;
+    uint64_t gather_rays;
 };
 
 // ---------------------------------------------------------------------------
@@ -571,12 +572,18 @@ inline C3 env_sample(const RtuSceneDesc& s, V3 dir) {
     return env_color_sample(s, s.environment, s.environment_map, uvw);
 }
 
-C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key);
+// The LightList a Shade() call receives: the scene's lights, or the one AmbientLight that MonteCarlo()
+// builds from its indirect estimate (RenderFunctions.cpp:585-590).
+struct LightSet {
+    const RtuLight* lights;
+    uint32_t n;
+};
+C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key, const LightSet& ls);
 
-inline C3 shade_node(Ctx& cx, const Hit& h, const Ray& ray, int bounce, uint32_t key) {
+inline C3 shade_node(Ctx& cx, const Hit& h, const Ray& ray, int bounce, uint32_t key, const LightSet& ls) {
     int mid = cx.s->nodes[h.node].material_id;
     if (mid < 0) return mkc(1, 1, 1);  // null material => white (reference would crash)
-    return shade(cx, mid, ray, h, bounce, key);
+    return shade(cx, mid, ray, h, bounce, key, ls);
 }
 
 // SampleSphere (RenderFunctions.cpp:282-301): a point of the cube [-radius, radius]^3, drawn again
@@ -609,14 +616,14 @@ inline V3 reflect_dir(V3 dir, V3 sn) {  // :207, :239, :280
 }
 
 // MtlBlinn::Shade (mtlFunctions.cpp:120-298)
-C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key) {
+C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount, uint32_t key, const LightSet& ls) {
     const RtuMaterial& m = cx.s->materials[mtl_id];
     const RtuSceneDesc& s = *cx.s;
     C3 result = mkc(0, 0, 0);
     C3 diffuse = mtl_color(s, mtl_id, RTU_MAP_DIFFUSE, m.diffuse, hInfo.uvw), specular = mtl_color(s, mtl_id, RTU_MAP_SPECULAR, m.specular, hInfo.uvw);
     if (hInfo.front) {  // :125
-        for (uint32_t i = 0; i < s.n_lights; i++) {
-            const RtuLight& l = s.lights[i];
+        for (uint32_t i = 0; i < ls.n; i++) {
+            const RtuLight& l = ls.lights[i];
             if (l.type == RTU_LIGHT_AMBIENT) {
                 result += diffuse * illuminate(cx, l, hInfo.p, key, i);  // :132
             } else {
@@ -658,7 +665,7 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount,
                 C3 absorptionV = mkc(expf((-rh.z) * absorption.r), expf((-rh.z) * absorption.g), expf((-rh.z) * absorption.b));  // :213, z==BIGFLOAT
                 cx.st.secondary_rays++;
                 if (trace(cx, reflected, 0, rh)) {
-                    C3 TIRResult = absorptionV * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_MAIN));
+                    C3 TIRResult = absorptionV * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_MAIN), ls);
                     result += TIRResult;
                 }
             } else {
@@ -675,9 +682,9 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount,
                     Hit rh = new_hit();
                     C3 frenselResult;
                     cx.st.secondary_rays++;
-                    if (trace(cx, reflected, 0, rh)) frenselResult = refraction * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_A));  // :247
+                    if (trace(cx, reflected, 0, rh)) frenselResult = refraction * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_A), ls);  // :247
                     else frenselResult = env_sample(s, reflected.dir);                                                             // :250
-                    C3 refractionResult = shade_node(cx, fh, refracted, bounceCount - 1, child_key(key, SLOT_MAIN));  // :254
+                    C3 refractionResult = shade_node(cx, fh, refracted, bounceCount - 1, child_key(key, SLOT_MAIN), ls);  // :254
                     C3 absorptionV = mkc(1, 1, 1);
                     if (!fh.front)
                         absorptionV = mkc(expf((-fh.z) * absorption.r), expf((-fh.z) * absorption.g), expf((-fh.z) * absorption.b));  // :259
@@ -694,11 +701,91 @@ C3 shade(Ctx& cx, int mtl_id, const Ray& ray, const Hit& hInfo, int bounceCount,
             Ray reflected; reflected.p = hInfo.p; reflected.dir = reflect_dir(ray.dir, sampledNormal);
             Hit rh = new_hit();
             cx.st.secondary_rays++;
-            if (trace(cx, reflected, 0, rh)) result += reflection * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_C));  // :286
+            if (trace(cx, reflected, 0, rh)) result += reflection * shade_node(cx, rh, reflected, bounceCount - 1, child_key(key, SLOT_C), ls);  // :286
             else result += env_sample(s, reflected.dir) * ldc(m.reflection);  // :289: reflection.GetColor(), not the sampled colour
         }
     }
     return result;
+}
+
+// ---------------------------------------------------------------------------
+// Recipe P (config 5): the Monte-Carlo gather of HEAD's Render() — MonteCarlo (RenderFunctions.cpp:549-590,
+// monteCarloBounces = 4, monteCarloSampleSize = 1) and SampleHemiSphereCosine (:320-337).
+#define RTU_GI_BOUNCES 4
+enum { SLOT_GATHER = 3, SLOT_AMBIENT_TREE = 4, DRAW_GATHER = 0x40000 };
+
+// acos of a float in [-1, 1], evaluated in binary64 with IEEE operations only (fdlibm's e_acos rational
+// approximation) and rounded to float — the device's stand-in for libm's acosf, as portable_sincos is for sinf/cosf.
+inline double acos_poly(double z) {
+    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
+                     z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+inline float portable_acos(float xf) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    const double x = (double)xf;
+    const double ax = fabs(x);
+    double r;
+    if (ax >= 1.0) r = x > 0 ? 0.0 : pi;                     // |x| == 1 (|x| > 1 cannot come from 1 - 2u)
+    else if (ax < 0.5) r = pio2_hi - (x - (pio2_lo - x * acos_poly(x * x)));
+    else if (x < 0) {
+        const double z = (1.0 + x) * 0.5, s = sqrt(z);
+        r = pi - 2.0 * (s + (acos_poly(z) * s - pio2_lo));
+    } else {
+        const double z = (1.0 - x) * 0.5, s = sqrt(z);
+        r = 2.0 * (s + acos_poly(z) * s);
+    }
+    return (float)r;
+}
+
+inline RtuLight ambient_light(C3 c) {  // AmbientLight::SetIntensity (:586-588)
+    RtuLight a;
+    memset(&a, 0, sizeof a);
+    a.type = RTU_LIGHT_AMBIENT;
+    a.intensity[0] = c.r; a.intensity[1] = c.g; a.intensity[2] = c.b;
+    return a;
+}
+
+// SampleHemiSphereCosine(origin, normal, 1.0), :320-337
+inline V3 sample_hemisphere_cosine(Ctx& cx, V3 normal, uint32_t key) {
+    const float radius = 1.0f;
+    float sampleX = draw(cx, key, DRAW_GATHER) / RAND_MAX_F;          // :324
+    float samplePhi = draw(cx, key, DRAW_GATHER + 1) / THETA_DIV;     // :325
+    float y = 1 - 2 * sampleX;
+    float sampleTheta = (float)(0.5 * (double)(cx.libm_trig ? acosf(y) : portable_acos(y)));  // :326
+    V3 v1 = normalized(cross(normal, mk(sampleX, sampleX, sampleX)));  // :329: Point3(sampleX)
+    V3 v2 = normalized(cross(v1, normal));                             // :330
+    float st, ct, sp, cp;
+    sincos_of(cx, sampleTheta, &st, &ct);
+    sincos_of(cx, samplePhi, &sp, &cp);
+    return (normal * (radius * ct) + v1 * ((radius * st) * cp)) + v2 * ((radius * st) * sp);  // :332-334
+}
+
+// MonteCarlo(list, hInfo, x, y, bounces, 1): returns the intensity of the AmbientLight it appends (:549-590).
+// key: the key of the Shade() calls at hInfo (its direct tree); gather draws use it too.
+C3 monte_carlo(Ctx& cx, const Hit& hInfo, int bounces, uint32_t key, const LightSet& scene_lights) {
+    C3 c = mkc(0, 0, 0);
+    if (bounces > 0) {
+        Hit h = new_hit();
+        V3 sampleOffset = sample_hemisphere_cosine(cx, hInfo.N, key);
+        Ray sampleRay; sampleRay.p = hInfo.p; sampleRay.dir = normalized(sampleOffset);  // :562
+        cx.gather_rays++;  // not among the ray counters: the reference harness cannot count these Trace calls either (same translation unit)
+        if (trace(cx, sampleRay, 0, h)) {  // :565
+            const uint32_t hkey = child_key(key, SLOT_GATHER);
+            C3 indirect = monte_carlo(cx, h, bounces - 1, hkey, scene_lights);  // :568
+            RtuLight amb = ambient_light(indirect);
+            LightSet mc = {&amb, 1};
+            c += shade_node(cx, h, sampleRay, RTU_MAX_BOUNCE, child_key(hkey, SLOT_AMBIENT_TREE), mc);  // :569
+            c += shade_node(cx, h, sampleRay, RTU_MAX_BOUNCE, hkey, scene_lights);                        // :570
+        } else {
+            c += env_sample(*cx.s, sampleRay.dir);  // :575
+        }
+        // :581: c /= (float)monteCarloSampleSize, a division by 1
+    } else {
+        c = mkc(0.1f, 0.1f, 0.1f);  // :584
+    }
+    return c;
 }
 
 // CalculateImageOrigin + CalculateCurrentPoint (RenderFunctions.cpp:243-269),
@@ -743,6 +830,7 @@ inline float halton(int index, int base) {
 struct Sampling {
     int spp;          // 0: recipe W (one ray through the pixel centre); S >= 1: recipe S, the sample loop of Render()
     bool sequential, libm_trig;
+    bool gi;          // recipe P: recipe S plus the Monte-Carlo gather of Render() (:129-134)
 };
 
 void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::atomic<int>* next_row, int y_begin,
@@ -752,9 +840,11 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
     cx.sequential = sm.sequential;
     cx.libm_trig = sm.libm_trig;
     cx.seq_key = cx.seq_counter = 0;
+    cx.gather_rays = 0;
     memset(&cx.st, 0, sizeof cx.st);
     const V3 up = ld3(s->camera.up);
     const V3 right = normalized(cross(normalized(ld3(s->camera.dir)), normalized(up)));
+    const LightSet scene_lights = {s->lights, s->n_lights};
     for (;;) {
         int y0 = next_row->fetch_add(chunk);
         if (y0 >= y_end) break;
@@ -772,7 +862,7 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
                     C3 c;
                     if (hit) {
                         cx.st.primary_hits++;
-                        c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, 0);  // :134-135
+                        c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, 0, scene_lights);  // :134-135
                     } else {
                         c = background_sample(*s, x, y);  // RenderFunctions.cpp:145
                     }
@@ -809,7 +899,15 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
                         cx.st.primary_hits++;
                         zSum += h.z;  // :109
                         numOfHits++;
-                        c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, key);  // :135
+                        if (sm.gi) {  // recipe P: :129-135
+                            C3 indirect = monte_carlo(cx, h, RTU_GI_BOUNCES, key, scene_lights);
+                            RtuLight amb = ambient_light(indirect);
+                            LightSet mc = {&amb, 1};
+                            c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, child_key(key, SLOT_AMBIENT_TREE), mc);  // :134
+                            c += shade_node(cx, h, ray, RTU_MAX_BOUNCE, key, scene_lights);                     // :135
+                        } else {
+                            c = shade_node(cx, h, ray, RTU_MAX_BOUNCE, key, scene_lights);  // :135
+                        }
                     } else {
                         c = background_sample(*s, x, y);  // :145
                     }
@@ -873,7 +971,7 @@ static int render_impl(const RtuSceneDesc* scene, int width, int height, int row
 
 int rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, float* rgbz_out,
                            RtuOracleStats* stats, int threads) {
-    Sampling sm = {0, false, false};
+    Sampling sm = {0, false, false, false};
     return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
 }
 
@@ -882,8 +980,21 @@ int rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height, 
     if (spp < 1 || (stream != RTU_ORACLE_STREAM_KEYED && stream != RTU_ORACLE_STREAM_SEQUENTIAL) ||
         (trig != RTU_ORACLE_TRIG_PORTABLE && trig != RTU_ORACLE_TRIG_LIBM))
         return RTU_ORACLE_ERR_ARG;
-    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM};
+    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, false};
     return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
+}
+
+int rtu_oracle_render_paths(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp, int stream,
+                            int trig, float* rgbz_out, RtuOracleStats* stats, int threads) {
+    if (spp < 1 || (stream != RTU_ORACLE_STREAM_KEYED && stream != RTU_ORACLE_STREAM_SEQUENTIAL) ||
+        (trig != RTU_ORACLE_TRIG_PORTABLE && trig != RTU_ORACLE_TRIG_LIBM))
+        return RTU_ORACLE_ERR_ARG;
+    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, true};
+    return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
+}
+
+void rtu_oracle_portable_acos(const float* x, int n, float* out) {
+    for (int i = 0; i < n; i++) out[i] = portable_acos(x[i]);
 }
 
 // sin, cos of the portable evaluation, for the test that bounds it against libm.

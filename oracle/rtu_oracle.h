@@ -45,7 +45,12 @@ int  rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* 
 #define RTU_ORACLE_TRIG_LIBM         1
 int  rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp,
                                int stream, int trig, float* rgbz_out, RtuOracleStats* stats, int threads);
+/* Recipe P (config 5): recipe S plus the Monte-Carlo gather of Render() (RenderFunctions.cpp:129-135: MonteCarlo
+ * with 4 bounces and 1 sample, :549-590; cosine-weighted hemisphere sampling, :320-337). */
+int  rtu_oracle_render_paths(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp,
+                             int stream, int trig, float* rgbz_out, RtuOracleStats* stats, int threads);
 void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* cos_out);
+void rtu_oracle_portable_acos(const float* x, int n, float* out);
 uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx);
 uint32_t rtu_oracle_sample_key(uint32_t pixel, uint32_t sample);
 uint32_t rtu_oracle_child_key(uint32_t key, uint32_t slot);

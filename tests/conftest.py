@@ -20,6 +20,7 @@ ALL_TAGS = SMALL_TAGS + FULL_TAGS
 TEX_TAGS = ["p7_200x150"]  # textured
 # stochastic effects, recipe S: glossy + soft + textured; depth of field; glossy + soft; 12 soft lights + glossy refraction; teapot + soft
 SAMPLED_TAGS = ["p10_s4_160x120", "p9_s3_160x120", "p11gs_s2_160x90", "p11x86_s1_120x90", "teapot1_s2_160x90"]
+PATH_TAGS = ["p11_p2_120x68", "p13_p2_96x72"]  # recipe P (config 5): + the Monte-Carlo gather
 
 
 def pytest_configure(config):

@@ -54,6 +54,9 @@ CONFIGS = [
     ("p11gs_s2_160x90", "Project11/scene_glossy_soft.xml", 160, 90, True, 2),
     ("p11x86_s1_120x90", "Project11/scene_86.xml", 120, 90, True, 1),
     ("teapot1_s2_160x90", "Teapot/scene.xml", 160, 90, True, 2),
+    # recipe P (config 5): recipe S plus the 4-bounce Monte-Carlo gather of Render(); 8th field "P"
+    ("p11_p2_120x68", "Project11/scene.xml", 120, 68, True, 2, "P"),
+    ("p13_p2_96x72", "Project13/scene.xml", 96, 72, True, 2, "P"),
 ]
 
 
@@ -66,9 +69,10 @@ def main():
     for cfg in CONFIGS:
         tag, scene, W, H, full = cfg[:5]
         spp = cfg[5] if len(cfg) > 5 else 0
+        paths = len(cfg) > 6 and cfg[6] == "P"
         if only and tag not in only:
             continue
-        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"] + ([str(spp)] if spp else []))
+        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"] + ([str(spp)] if spp else []) + (["paths"] if paths else []))
         src = os.path.join(REPO, "oracle", "_ref", "out", tag)
         dst = os.path.join(HERE, tag)
         os.makedirs(dst, exist_ok=True)
@@ -83,7 +87,7 @@ def main():
         z8 = np.fromfile(os.path.join(src, "zbuffer.u8"), np.uint8).reshape(H, W)
         stats = json.load(open(os.path.join(src, "stats.json")))
         meta = {
-            "scene": scene, "width": W, "height": H, "recipe": "S" if spp else "W", "spp": spp,
+            "scene": scene, "width": W, "height": H, "recipe": "P" if paths else "S" if spp else "W", "spp": spp,
             "stream": "sequential" if spp else None,
             "primary": stats["primary"], "primary_hits": stats["primary_hits"],
             "secondary": stats["secondary"], "shadow": stats["shadow"],

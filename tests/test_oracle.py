@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import REFERENCE, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, read_png, sha256
+from conftest import PATH_TAGS, REFERENCE, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, read_png, sha256
 
 
 @pytest.mark.parametrize("tag", SMALL_TAGS + TEX_TAGS)
@@ -200,3 +200,38 @@ def test_sample_stream_known_answers(orc):
         assert orc.lib.rtu_oracle_sample_key(pix, smp) == want
     for key, slot in ((5, 0), (0xffffffff, 2)):
         assert orc.lib.rtu_oracle_child_key(key, slot) == mix32((key + (slot + 1) * 0x632be5ab) & 0xFFFFFFFF)
+
+
+# ---- recipe P: the Monte-Carlo gather of config 5 ---------------------------------------------------
+@pytest.mark.parametrize("tag", PATH_TAGS)
+def test_oracle_recipe_p_bit_exact_vs_reference_golden(pkg, orc, golden, tag):
+    """MonteCarlo() (4 bounces, cosine-weighted hemisphere, an AmbientLight per level) as HEAD's Render()
+    calls it, against the reference built with rand() wrapped to the sequential stream: every bit of z and RGB."""
+    g = golden(tag)
+    assert g.meta["recipe"] == "P"
+    out, st = orc.render_paths(g.scene(pkg), g.width, g.height, g.meta["spp"], stream=orc.STREAM_SEQUENTIAL,
+                               trig=orc.TRIG_LIBM, threads=4)
+    assert np.array_equal(out[..., 3].view(np.uint32), g.npz["z"].view(np.uint32)), "z differs"
+    assert np.array_equal(out[..., :3].view(np.uint32), g.npz["rgb"].view(np.uint32)), "linear RGB differs"
+    assert (st["primary_hits"], st["secondary_rays"], st["shadow_rays"]) == (g.meta["primary_hits"], g.meta["secondary"], g.meta["shadow"])
+    # with the portable acos / sincos a few percent of the pixels move in their last bits, nothing more
+    port, _ = orc.render_paths(g.scene(pkg), g.width, g.height, g.meta["spp"], stream=orc.STREAM_SEQUENTIAL,
+                               trig=orc.TRIG_PORTABLE, threads=4)
+    d = np.abs(port[..., :3] - g.npz["rgb"])
+    assert (d > 0).any(-1).mean() < 0.15 and np.median(d) == 0
+
+
+def test_portable_acos_within_one_ulp_of_libm(orc):
+    rng = np.random.default_rng(11)
+    x = np.concatenate([1 - 2 * rng.random(300000, dtype=np.float32), np.float32([-1, 1, 0, 0.5, -0.5, 1e-20, 0.99999994, -0.99999994])])
+    got = orc.portable_acos(x)
+    want = np.arccos(x.astype(np.float64))
+    ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(got.astype(np.float64) - want) <= 0.5000001 * ulp + 1e-300), "not correctly rounded"
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.acosf.restype = ctypes.c_float
+    libm.acosf.argtypes = [ctypes.c_float]
+    la = np.array([libm.acosf(float(v)) for v in x[:20000]], np.float32)
+    dd = np.abs(got[:20000].view(np.int32).astype(np.int64) - la.view(np.int32).astype(np.int64))
+    assert dd.max() <= 1 and (dd != 0).mean() < 0.12  # glibc acosf is within 1 ulp, not correctly rounded

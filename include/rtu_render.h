@@ -70,6 +70,11 @@ typedef struct RtuFrameDesc {
     float   lens_up[3];               /* camera.up (as given) and normalize(dir x up): the lens disk of */
     float   lens_right[3];            /* RenderFunctions.cpp:93 */
     float   dof;                      /* camera.dof */
+    int32_t gather_bounces;           /* 0, or 4 with samples >= 1: recipe P (config 5) — recipe S plus the Monte-Carlo gather
+                                         of Render() (RenderFunctions.cpp:129-135: MonteCarlo with monteCarloBounces = 4 and one
+                                         cosine-weighted hemisphere sample per bounce, :549-590, :320-337). Keys: the hit of the
+                                         gather ray has child_key(key, 3), the Shade() tree lit by MonteCarlo()'s AmbientLight
+                                         child_key(key, 4); purposes 0x40000, 0x40001: sampleX, samplePhi */
 } RtuFrameDesc;
 
 /* Sample streams of recipe S. The reference draws from rand() (shared by its threads, seeded with the

@@ -899,7 +899,7 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
                         cx.st.primary_hits++;
                         zSum += h.z;  // :109
                         numOfHits++;
-                        if (sm.gi) {  // recipe P: :129-135
+                        if (sm.gi && s->nodes[h.node].material_id >= 0) {  // recipe P: :129-135
                             C3 indirect = monte_carlo(cx, h, RTU_GI_BOUNCES, key, scene_lights);
                             RtuLight amb = ambient_light(indirect);
                             LightSet mc = {&amb, 1};

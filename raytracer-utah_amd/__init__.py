@@ -70,7 +70,7 @@ class RtuFrameDesc(ctypes.Structure):
                 ("shard_count", ctypes.c_int32), ("max_bounce", ctypes.c_int32), ("collect_stats", ctypes.c_int32),
                 ("coop_threshold", ctypes.c_int32), ("samples", ctypes.c_int32), ("cam_pos", ctypes.c_float * 3), ("origin", ctypes.c_float * 3),
                 ("u", ctypes.c_float * 3), ("v", ctypes.c_float * 3), ("lens_up", ctypes.c_float * 3), ("lens_right", ctypes.c_float * 3),
-                ("dof", ctypes.c_float)]
+                ("dof", ctypes.c_float), ("gather_bounces", ctypes.c_int32)]
 
 
 STAT_FIELDS = ("primary_rays", "primary_hits", "secondary_rays", "shadow_rays", "node_tests", "mesh_entries",
@@ -251,7 +251,7 @@ class Scene:
             pass
 
 
-def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stats=False, max_bounce=5, samples=0):
+def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stats=False, max_bounce=5, samples=0, gather_bounces=0):
     f = RtuFrameDesc()
     rc = hip.rtu_frame_setup(ctypes.byref(camera), width, height, ctypes.byref(f))
     if rc != RTU_OK:
@@ -260,6 +260,7 @@ def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stat
     f.collect_stats = 1 if collect_stats else 0
     f.max_bounce = max_bounce
     f.samples = samples  # 0: recipe W; S >= 1: recipe S (soft shadows, glossy bounces, depth of field)
+    f.gather_bounces = gather_bounces  # 4 (with samples): recipe P, + the Monte-Carlo gather of config 5
     return f
 
 

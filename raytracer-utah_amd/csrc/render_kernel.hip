@@ -47,6 +47,9 @@ namespace {
 // bit 2: the launch renders a batch of FRAMES of recipe W (rtu_render_frames_device), each with its own
 // camera; its pixel index space is [frame in batch][pixel of the shard], like a batch of samples
 #define BATD ((TEX & 4) != 0)
+// bit 3: recipe P (with bit 1): the launches of the Monte-Carlo gather — chain tracing and the two Shade()
+// trees per chain hit, one of them lit by MonteCarlo()'s AmbientLight
+#define GID ((TEX & 8) != 0)
 
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
 // k_trace slot selection bits
@@ -122,10 +125,11 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
 template <int TEX>
-__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp) {
+__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp, bool amb = false) {
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
     uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
-    if (front && s.n_lights > 0) info |= RTU_FI_SH;                      // mtlFunctions.cpp:125
+    if (amb) info |= RTU_FI_AMB;                                         // the light list is one AmbientLight: no shadow rays
+    else if (front && s.n_lights > 0) info |= RTU_FI_SH;                 // mtlFunctions.cpp:125
     if (bounce > 0) {                                                   // :158
         if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
             info |= RTU_FI_MAIN;
@@ -148,6 +152,46 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
     if (info & RTU_FI_TIR) return reflect_dir(dir, t.sn);    // :207, the first sample
     if (slot == SLOT_A) return reflect_dir(dir, t.sn2);      // :239, the second sample shadows the first
     return norm3((-t.sn2) * t.cosTheta2 + t.SVector * t.sinTheta2);  // :229
+}
+
+// Append a level-0 frame (a Shade() call at a primary or, recipe P, a chain hit) and its entries in the two
+// slot lists: three appends issued back to back, one wait for the wavefront instead of three. Wave-uniform
+// call; `want` says whether the lane has a frame. Returns the frame index or ~0u.
+template <int TEX>
+__device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, uint32_t shard, uint32_t info, f3 p, f3 N, uint32_t fbw, f3 dir,
+                                                float fcw, f3 uvw) {
+    const LevelBuffers& lv = a.lv[0];
+    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+    const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
+    const unsigned long long mf = __ballot(want), mm = __ballot(wm), mc = __ballot(wc);
+    uint32_t bf = 0, bm = 0, bc = 0;
+    if (mf) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
+        if ((threadIdx.x & 63u) == leader) {
+            bf = atomicAdd(&a.fcnt->n_frames[0][shard], (uint32_t)__popcll(mf));
+            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][shard], (uint32_t)__popcll(mm));
+            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][shard], (uint32_t)__popcll(mc));
+        }
+        bf = (uint32_t)__shfl((int)bf, (int)leader);
+        bm = (uint32_t)__shfl((int)bm, (int)leader);
+        bc = (uint32_t)__shfl((int)bc, (int)leader);
+    }
+    uint32_t idx = ~0u;
+    if (want) {
+        const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
+        if (fl < lv.cap_s) {  // level 0 is sized for every root of the launch (ensure_levels): always true
+            idx = fl + shard * lv.cap_s;
+            if (TEXD) lv.fuv[idx] = make_float4(uvw.x, uvw.y, uvw.z, 0.0f);
+            lv.fa[idx] = make_float4(p.x, p.y, p.z, __uint_as_float(info));
+            lv.fb[idx] = make_float4(N.x, N.y, N.z, __uint_as_float(fbw));
+            lv.fc[idx] = make_float4(dir.x, dir.y, dir.z, fcw);
+            if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
+            if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
+        } else {
+            a.fcnt->overflow = 1;
+        }
+    }
+    return idx;
 }
 
 // A sampled launch renders a.batch consecutive samples of the frame at once (longer ray lists fill the chip
@@ -175,7 +219,7 @@ __device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) 
     smp.key = 0;
     if (smp.on) {
         const uint32_t w = __float_as_uint(fbw);
-        if (L == 0) {
+        if (L == 0 && !GID) {
             int x, y;
             uint32_t sidx;
             pixel_of<TEX>(a, w, x, y, sidx);
@@ -258,6 +302,33 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     Smp smp;
     smp.on = SMPD;
     smp.key = 0;
+    if (GID && a.gi_depth > 0) {
+        // recipe P, chain depth k > 0: the gather ray from the hit of depth k - 1 (RenderFunctions.cpp:556-565)
+        const size_t hb = (size_t)(a.gi_depth - 1u) * 4u * a.gi_total + pix;
+        float4 hA = make_float4(0, 0, 0, 0), hB = hA, hC = hA;
+        if (valid) { hA = a.gi_h[hb]; hB = a.gi_h[hb + a.gi_total]; hC = a.gi_h[hb + 2u * (size_t)a.gi_total]; }
+        const size_t ho = (size_t)a.gi_depth * 4u * a.gi_total + pix;
+        if (valid && !(__float_as_uint(hB.w) & 1u)) {  // the chain ended above: no hit at this depth either
+            if (leader) a.gi_h[ho + a.gi_total] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+            valid = false;
+        }
+        if (valid) {
+            const uint32_t pkey = __float_as_uint(hC.w);
+            const f3 sampleOffset = sample_hemisphere_cosine(mk3(hB.x, hB.y, hB.z), pkey);
+            ray.p = mk3(hA.x, hA.y, hA.z);
+            ray.dir = norm3(sampleOffset);  // :562
+            smp.key = child_key(pkey, RTU_SLOT_GATHER);
+            bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+            if (!deferred && leader) {
+                const int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
+                a.gi_h[ho] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+                a.gi_h[ho + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2)));
+                a.gi_h[ho + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
+                if (TEXD) a.gi_h[ho + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+            }
+        }
+        return;
+    }
     if (valid) {
         float ox = 0.5f, oy = 0.5f;  // recipe W: the pixel centre
         if (smp.on) {
@@ -288,43 +359,19 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
                 if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
                 else want = true;
             }
+            if (GID) {  // recipe P: the chain's depth-0 record instead of a frame; a null material stays white
+                a.gi_h[pix] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
+                a.gi_h[pix + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((want ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(mid + 1) << 2)));
+                a.gi_h[pix + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
+                if (TEXD) a.gi_h[pix + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+                want = false;
+            }
         }
     }
-    // the frame's info word first, then its three appends (frame array, the two slot lists) issued
-    // back to back: one wait for the wavefront instead of three
+    if (GID) return;
     uint32_t info = 0;
     if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
-    const LevelBuffers& lv = a.lv[0];
-    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
-    const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
-    const unsigned long long mf = __ballot(want), mm = __ballot(wm), mc = __ballot(wc);
-    uint32_t bf = 0, bm = 0, bc = 0;
-    if (mf) {
-        const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
-        if ((threadIdx.x & 63u) == leader) {
-            bf = atomicAdd(&a.fcnt->n_frames[0][shard], (uint32_t)__popcll(mf));
-            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][shard], (uint32_t)__popcll(mm));
-            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][shard], (uint32_t)__popcll(mc));
-        }
-        bf = (uint32_t)__shfl((int)bf, (int)leader);
-        bm = (uint32_t)__shfl((int)bm, (int)leader);
-        bc = (uint32_t)__shfl((int)bc, (int)leader);
-    }
-    if (want) {
-        const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
-        if (fl < lv.cap_s) {
-            const uint32_t idx = fl + shard * lv.cap_s;
-            if (TEXD) lv.fuv[idx] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
-            lv.fa[idx] = make_float4(h.p.x, h.p.y, h.p.z, __uint_as_float(info));
-            lv.fb[idx] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(pix));
-            lv.fc[idx] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, h.z);
-            // (level 0 is sized for every tile of the launch, ensure_levels: fl < cap_s always holds)
-            if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
-            if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
-        } else {
-            a.fcnt->overflow = 1;
-        }
-    }
+    append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
@@ -683,6 +730,13 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
 
     // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
     f3 direct = mk3(0, 0, 0);
+    f3 ambI = mk3(0, 0, 0);
+    if (GID && active && (info & RTU_FI_AMB)) {
+        // the light list is MonteCarlo()'s one AmbientLight: result += diffuse * intensity on front faces (:125-132)
+        const float4 t = lv.famb[f];
+        ambI = mk3(t.x, t.y, t.z);
+        if (info & RTU_FI_FRONT) direct = direct + mtl_color<TEXD>(s, (int)(info & RTU_FI_MTL_MASK), RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw) * ambI;
+    }
     if (active && (info & RTU_FI_SH)) {
         const int mtl = (int)(info & RTU_FI_MTL_MASK);
         const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
@@ -787,10 +841,11 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
                 cuvw = mk3(t.x, t.y, t.z);
                 nx.fuv[idx] = t;
             }
-            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp);
+            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp, GID && (info & RTU_FI_AMB));
             nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
             nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(BATD ? entry : csmp.key));
-            nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, s0[k].w);
+            nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, GID ? fc.w : s0[k].w);  // recipe P: the chain id travels down
+            if (GID && (info & RTU_FI_AMB)) nx.famb[idx] = make_float4(ambI.x, ambI.y, ambI.z, 0.0f);
             st[k] = (int)idx;
             wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
             wantRefl[k] = (cinfo & RTU_FI_C) != 0;
@@ -832,8 +887,10 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     if (!pending) {
         const f3 one = mk3(1, 1, 1);
         const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw, smp);
-        if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-        else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+        if (L == 0) {
+            if (GID) a.gi_res[((info & RTU_FI_AMB) ? 0u : a.gi_total) + (size_t)__float_as_uint(fc.w)] = make_float4(r.x, r.y, r.z, 0.0f);
+            else a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+        } else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
     } else {
         lv.fres[f] = make_float4(direct.x, direct.y, direct.z, 0.0f);  // the direct term waits for the children
     }
@@ -892,8 +949,10 @@ __device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32
     }
     const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw,
                                frame_smp<TEX>(a, L, fb.w));
-    if (L == 0) a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-    else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
+    if (L == 0) {
+        if (GID) a.gi_res[((info & RTU_FI_AMB) ? 0u : a.gi_total) + (size_t)__float_as_uint(fc.w)] = make_float4(r.x, r.y, r.z, 0.0f);
+        else a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
+    } else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
 }
 
 template <int TEX>
@@ -1079,8 +1138,84 @@ __global__ void k_selftest_prims(unsigned long long n_rays, unsigned long long s
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// ---- recipe P: MonteCarlo() of RenderFunctions.cpp:549-590 unrolled over the chain ---------------------
+// Depth k of a chain is shaded after depth k + 1: the AmbientLight MonteCarlo(h_k, 4 - k) appends has the
+// intensity c = Shade(h_k+1, its own AmbientLight) + Shade(h_k+1, lights) (:568-570), the environment along
+// the gather ray if it missed (:575), or 0.1 at the last bounce (:584). This kernel computes c for every
+// chain that has a hit of depth a.gi_depth and appends the two Shade() trees of that hit as level-0 frames.
+template <int TEX>
+__global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
+    const DevScene& s = a.scene;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = a.gi_depth;
+    const uint32_t chunks = (a.gi_total + 63u) / 64u;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t chain = c * 64u + lane;
+        const uint32_t shard = c % RTU_SHARDS;
+        const size_t hb = (size_t)k * 4u * a.gi_total + chain;
+        float4 hA = make_float4(0, 0, 0, 0), hB = hA, hC = hA, hD = hA;
+        bool want = false;
+        if (chain < a.gi_total) {
+            hB = a.gi_h[hb + a.gi_total];
+            want = (__float_as_uint(hB.w) & 1u) != 0;
+        }
+        if (want) {
+            hA = a.gi_h[hb];
+            hC = a.gi_h[hb + 2u * (size_t)a.gi_total];
+            if (TEXD) hD = a.gi_h[hb + 3u * (size_t)a.gi_total];
+        }
+        const uint32_t pk = __float_as_uint(hB.w);
+        const int mid = (int)(pk >> 2) - 1;
+        f3 amb = mk3(0.1f, 0.1f, 0.1f);  // :584
+        if (want && k < (uint32_t)RTU_GI_BOUNCES) {
+            const size_t hn = (size_t)(k + 1u) * 4u * a.gi_total + chain;
+            const uint32_t npk = __float_as_uint(a.gi_h[hn + a.gi_total].w);
+            if (npk & 1u) {
+                if ((int)(npk >> 2) - 1 < 0) {
+                    amb = (mk3(0, 0, 0) + mk3(1, 1, 1)) + mk3(1, 1, 1);  // a node without material shades white, twice
+                } else {
+                    const float4 ra = a.gi_res[chain], rd = a.gi_res[(size_t)a.gi_total + chain];
+                    amb = (mk3(0, 0, 0) + mk3(ra.x, ra.y, ra.z)) + mk3(rd.x, rd.y, rd.z);  // :569-570
+                }
+            } else {
+                const float4 nd = a.gi_h[hn + 2u * (size_t)a.gi_total];
+                amb = mk3(0, 0, 0) + ((TEXD && s.env.has_map) ? env_sample(s, mk3(nd.x, nd.y, nd.z)) : ld3(s.environment));  // :575
+            }
+        }
+        if (want && mid < 0) {  // no material at this hit: both trees are white, nothing to trace
+            a.gi_res[chain] = make_float4(1, 1, 1, 0);
+            a.gi_res[(size_t)a.gi_total + chain] = make_float4(1, 1, 1, 0);
+            want = false;
+        }
+        const f3 p = mk3(hA.x, hA.y, hA.z), N = mk3(hB.x, hB.y, hB.z), dir = mk3(hC.x, hC.y, hC.z), uvw = mk3(hD.x, hD.y, hD.z);
+        const bool front = (pk & 2u) != 0;
+        Smp sd, sa;
+        sd.on = sa.on = true;
+        sd.key = __float_as_uint(hC.w);                        // the tree lit by the scene's lights (:570, :135)
+        sa.key = child_key(sd.key, RTU_SLOT_AMBIENT_TREE);     // the tree lit by the AmbientLight (:569, :134)
+        uint32_t ia = 0, id = 0;
+        if (want) {
+            ia = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
+            id = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
+        }
+        const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw);
+        if (want && fa_idx != ~0u) a.lv[0].famb[fa_idx] = make_float4(amb.x, amb.y, amb.z, 0.0f);
+        append_root<TEX>(a, want, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw);
+    }
+}
+
+// the pixel of a chain: Shade(h_0, AmbientLight) + Shade(h_0, lights) (:134-135), z of the primary hit
+__global__ void __launch_bounds__(256) k_gi_final(KernelArgs a) {
+    const uint32_t chain = blockIdx.x * 256u + threadIdx.x;
+    if (chain >= a.gi_total) return;
+    const uint32_t pk = __float_as_uint(a.gi_h[(size_t)a.gi_total + chain].w);
+    if (!(pk & 1u)) return;  // missed (background) or a node without material (white): written by the chain's first launch
+    const float4 ra = a.gi_res[chain], rd = a.gi_res[(size_t)a.gi_total + chain];
+    a.out[chain] = make_float4(ra.x + rd.x, ra.y + rd.y, ra.z + rd.z, a.gi_h[chain].w);
+}
+
 template <int STACK, int TEX>
-int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream) {
+int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
     // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
@@ -1088,7 +1223,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     const dim3 gridT(8192), gridN(8192), gridS(8192), gridF(2048), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
-    if (stats) {
+    if (mode == RTU_LAUNCH_SHADE) {
+        hipLaunchKernelGGL((k_gi_roots<TEX>), gridN, block, 0, stream, a);
+    } else if (stats) {
         hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         hipLaunchKernelGGL((k_primary<STACK, false, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
@@ -1097,6 +1234,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
         }
     }
+    if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
     // levels >= tail_from are evaluated by k_tail (fast variant only; the host passes tail_from >= 1, or 6 for none)
     const int regular = (!stats && a.tail_from >= 1 && a.tail_from < levels) ? a.tail_from : levels;
     for (int L = 0; L < regular; L++) {
@@ -1175,9 +1313,13 @@ static int launch_feat(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_st
     return launch_all<RTU_MAX_BVH_STACK, FEAT>(args, n_tiles, stats, stream);
 }
 
-int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
-    // textured scenes and sampled frames run their own instantiations: the others carry no uvw, sample
-    // nothing and draw nothing
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode) {
+    // textured scenes, sampled frames and batches of frames run their own instantiations: the others carry no
+    // uvw, sample nothing and draw nothing. Recipe P has one stack size (the largest).
+    if (mode != RTU_LAUNCH_ALL) {
+        if (args.scene.textured) return launch_all<RTU_MAX_BVH_STACK, 11>(args, n_tiles, stats, stream, mode);
+        return launch_all<RTU_MAX_BVH_STACK, 10>(args, n_tiles, stats, stream, mode);
+    }
     switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0))) {
         case 0: return launch_feat<0>(args, n_tiles, bvh_stack_needed, stats, stream);
         case 1: return launch_feat<1>(args, n_tiles, bvh_stack_needed, stats, stream);
@@ -1186,4 +1328,9 @@ int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stac
         case 4: return launch_feat<4>(args, n_tiles, bvh_stack_needed, stats, stream);
         default: return launch_feat<5>(args, n_tiles, bvh_stack_needed, stats, stream);
     }
+}
+
+int rtu_launch_gi_final(const KernelArgs& args, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gi_final, dim3((args.gi_total + 255u) / 256u), dim3(256), 0, stream, args);
+    return (int)hipGetLastError();
 }

@@ -43,6 +43,10 @@ struct RtuContext {
     size_t    acc_pixels = 0;
     float4*   sample_buf = nullptr;      // the images of one batch of samples, [sample][pixel]
     size_t    sample_buf_pixels = 0;
+    float4*   gi_h = nullptr;            // recipe P: chain records [5 depths][4][chains], results [2][chains]
+    float4*   gi_res = nullptr;
+    size_t    gi_chains = 0;
+    bool      want_gi = false;           // level buffers carry famb
     // k_tail: the recursion level from which the previous frame of this scene was almost empty (a hint —
     // any value renders the same image); last_tail_from: what the most recent frame was launched with
     int      tail_hint = RTU_MAX_LEVELS, last_tail_from = RTU_MAX_LEVELS;
@@ -500,6 +504,8 @@ int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
     if (f->shard_count < 1 || f->shard_rank < 0 || f->shard_rank >= f->shard_count) return fail(ctx, RTU_ERR_ARG, "bad shard");
     if (f->max_bounce < 0 || f->max_bounce > RTU_MAX_BOUNCE) return fail(ctx, RTU_ERR_ARG, "max_bounce out of range");
     if (f->samples < 0 || f->samples > 65536) return fail(ctx, RTU_ERR_ARG, "samples out of range");
+    if (f->gather_bounces != 0 && (f->gather_bounces != RTU_GI_BOUNCES || f->samples < 1))
+        return fail(ctx, RTU_ERR_ARG, "gather_bounces is 0 or %d (recipe P, with samples >= 1)", RTU_GI_BOUNCES);
     if (f->samples == 0 && ctx->has_scene && (ctx->scene_stochastic || f->dof != 0))
         return fail(ctx, RTU_ERR_STOCHASTIC, "the scene has %s: render it with frame.samples >= 1 (recipe S)",
                     ctx->scene_stochastic ? ctx->stochastic_what.c_str() : "depth of field");
@@ -526,14 +532,15 @@ int alloc_level(RtuContext* ctx, T** dst, size_t count) {
 // pixel; a deeper level starts with the same capacity and is grown to what an overflowed frame
 // reported (check_overflow) — a frame can hold up to 3^L frames per pixel at level L in theory,
 // a tenth of a frame per pixel in the reference's scenes.
-int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles) {
+int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = false) {
+    if (gi) ctx->want_gi = true;
     // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile of the launch (ragged right /
     // bottom tiles included), so level 0 cannot overflow
     size_t tiles = n_tiles;
     size_t cap_s0 = ((tiles + RTU_SHARDS - 1) / RTU_SHARDS) * 64;
     size_t want[RTU_MAX_LEVELS];
     size_t maxcap = cap_s0;
-    bool fits = ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv);
+    bool fits = ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv) && (!ctx->want_gi || ctx->lv[0].famb);
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         want[L] = L == 0 || ctx->want_cap_s[L] < cap_s0 ? cap_s0 : ctx->want_cap_s[L];
         if (want[L] > maxcap) maxcap = want[L];
@@ -561,6 +568,7 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles) {
         if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
         if ((rc = alloc_level(ctx, &lv.fpend, cap)) != RTU_OK) return rc;
+        if (ctx->want_gi && (rc = alloc_level(ctx, &lv.famb, cap)) != RTU_OK) return rc;
         if (ctx->textured) {
             if ((rc = alloc_level(ctx, &lv.fuv, cap)) != RTU_OK) return rc;
             if ((rc = alloc_level(ctx, &lv.fsuv, cap * 3)) != RTU_OK) return rc;
@@ -590,14 +598,29 @@ float halton(int index, int base) {
 // One launch sequence: the whole frame of recipe W, or samples [sample_index, sample_index + batch) of
 // recipe S into d_out as [sample][pixel of the shard].
 // frames_batch: `batch` frames of recipe W with their own cameras (frame == &frames_batch[0]).
+// gi_mode RTU_LAUNCH_CHAIN / RTU_LAUNCH_SHADE: one step of recipe P at chain depth gi_depth (render_sampled).
 int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters, int sample_index = 0, int batch = 1,
-           const RtuFrameDesc* frames_batch = nullptr) {
+           const RtuFrameDesc* frames_batch = nullptr, int gi_mode = RTU_LAUNCH_ALL, int gi_depth = 0) {
     uint32_t tiles_x = (uint32_t)((frame->width + 7) / 8);
     uint32_t bands = (uint32_t)shard_bands(frame->height, frame->shard_rank, frame->shard_count);
     uint32_t n_tiles = tiles_x * bands * (uint32_t)batch;
     uint32_t pixels = (uint32_t)rtu_shard_rows(frame) * (uint32_t)frame->width;
-    int rc = ensure_levels(ctx, pixels * (uint32_t)batch, n_tiles);
+    const bool gi = gi_mode != RTU_LAUNCH_ALL;
+    // recipe P: every chain hit is the root of two Shade() trees
+    int rc = ensure_levels(ctx, pixels * (uint32_t)batch, gi ? 2u * (n_tiles + RTU_SHARDS) : n_tiles, gi);
     if (rc != RTU_OK) return rc;
+    if (gi) {
+        const size_t chains = (size_t)pixels * (size_t)batch;
+        if (chains > ctx->gi_chains) {
+            if (ctx->gi_h) (void)hipFree(ctx->gi_h);
+            if (ctx->gi_res) (void)hipFree(ctx->gi_res);
+            ctx->gi_h = ctx->gi_res = nullptr;
+            ctx->gi_chains = 0;
+            RTU_HIP(ctx, hipMalloc((void**)&ctx->gi_h, chains * (RTU_GI_BOUNCES + 1) * 4 * sizeof(float4)));
+            RTU_HIP(ctx, hipMalloc((void**)&ctx->gi_res, chains * 2 * sizeof(float4)));
+            ctx->gi_chains = chains;
+        }
+    }
     bool stats = frame->collect_stats != 0;
     if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
     RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, sizeof(FrameCounters), stream));
@@ -643,10 +666,23 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
             memcpy(a.cam[b].v, frames_batch[b].v, sizeof a.cam[b].v);
         }
     }
+    if (gi) {
+        a.gi_h = ctx->gi_h;
+        a.gi_res = ctx->gi_res;
+        a.gi_depth = (uint32_t)gi_depth;
+        a.gi_total = pixels * (uint32_t)batch;
+    }
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
-    hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream);
+    if (gi_mode == RTU_LAUNCH_SHADE && gi_depth == 0) {
+        hipError_t e0 = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
+        if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
+        e0 = (hipError_t)rtu_launch_gi_final(a, stream);  // harmless if this step has to be repeated: it only reads the results
+        if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
+        return RTU_OK;
+    }
+    hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return RTU_OK;
 }
@@ -712,7 +748,8 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
 int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_t stream, bool zero_counters) {
     const size_t pixels = (size_t)rtu_shard_rows(frame) * (size_t)frame->width;
     if (pixels == 0) return RTU_OK;
-    int batch = (int)(((size_t)1 << 25) / pixels);
+    const bool gi = frame->gather_bounces != 0;
+    int batch = (int)(((size_t)1 << (gi ? 23 : 25)) / pixels);  // recipe P keeps 22 float4 per chain
     if (batch > RTU_MAX_BATCH) batch = RTU_MAX_BATCH;
     if (batch > frame->samples) batch = frame->samples;
     if (batch < 1) batch = 1;
@@ -736,7 +773,7 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
     int rounds = 0;
     for (int i = 0; i < frame->samples; i += batch) {
         int nb;
-        for (;;) {
+        for (; !gi;) {
             nb = frame->samples - i < batch ? frame->samples - i : batch;
             int rc = launch(ctx, frame, ctx->sample_buf, stream, zero_counters && i == 0, i, nb);
             if (rc != RTU_OK) return rc;
@@ -746,6 +783,27 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
             if (!overflow) break;
             if (++rounds > 4 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
             if (frame->collect_stats) { i = 0; zero_counters = true; }  // the counters of the dropped pass are in the totals: start again
+        }
+        if (gi) {
+            // recipe P: the chain of gather rays first (depth 0 = the primary ray), then the Shade() trees from the
+            // deepest hit up — each depth's AmbientLight needs the results of the depth below (k_gi_roots)
+            nb = frame->samples - i < batch ? frame->samples - i : batch;
+            if (frame->collect_stats) return fail(ctx, RTU_ERR_ARG, "the counting variant does not cover recipe P");
+            for (int k = 0; k <= RTU_GI_BOUNCES; k++) {
+                int rc = launch(ctx, frame, ctx->sample_buf, stream, false, i, nb, nullptr, RTU_LAUNCH_CHAIN, k);
+                if (rc != RTU_OK) return rc;
+            }
+            for (int k = RTU_GI_BOUNCES; k >= 0; k--) {
+                for (;;) {
+                    int rc = launch(ctx, frame, ctx->sample_buf, stream, false, i, nb, nullptr, RTU_LAUNCH_SHADE, k);
+                    if (rc != RTU_OK) return rc;
+                    RTU_HIP(ctx, hipStreamSynchronize(stream));
+                    bool overflow = false;
+                    if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
+                    if (!overflow) break;  // (a repeated step reads the same chain records and results of depth k + 1)
+                    if (++rounds > 8 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
+                }
+            }
         }
         hipError_t e = (hipError_t)rtu_launch_accumulate(ctx->sample_buf, (uint32_t)nb, ctx->acc, ctx->acc_hits, (uint32_t)pixels, i == 0, stream);
         if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -815,6 +873,8 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);
     if (ctx->sample_buf) (void)hipFree(ctx->sample_buf);
+    if (ctx->gi_h) (void)hipFree(ctx->gi_h);
+    if (ctx->gi_res) (void)hipFree(ctx->gi_res);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

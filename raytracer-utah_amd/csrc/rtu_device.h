@@ -115,6 +115,7 @@ struct DevScene {
 #define RTU_FI_MAIN       (1u << 23)      // refraction property exists and bounce > 0 (:158-160)
 #define RTU_FI_TIR        (1u << 24)      // sinTheta2 > 1 (:205): the main ray is the TIR reflection
 #define RTU_FI_C          (1u << 25)      // reflection property exists and bounce > 0 (:273)
+#define RTU_FI_AMB        (1u << 26)      // recipe P: this Shade() tree receives MonteCarlo()'s one AmbientLight (LevelBuffers::famb) instead of the scene's lights
 
 // child status codes in fchild
 #define RTU_CH_NONE   (-1)   // slot not active
@@ -134,6 +135,7 @@ struct LevelBuffers {
     uint32_t* lmain; // [cap] per shard: the frames (index within the shard) that fire a refracted / TIR (and Fresnel) ray
     uint32_t* lrefl; // [cap] per shard: the frames that fire a mirror ray — k_trace visits these lists for the secondary slots
     uint32_t* fpend; // [cap] per shard: the frames (index within the shard) that wait for children — what k_combine visits
+    float4* famb;    // recipe P only: [cap] intensity of the AmbientLight of a RTU_FI_AMB frame
     uint32_t cap_s;  // capacity of ONE shard; frame id = shard * cap_s + index within the shard
     uint32_t pad;
 };
@@ -193,6 +195,13 @@ struct KernelArgs {
     uint32_t     sample_index;      // first sample of the batch
     uint32_t     batch, batch_pixels, tiles_per_image;
     float        pix_off_x[RTU_MAX_BATCH], pix_off_y[RTU_MAX_BATCH];  // currentOffset + Halton(index, 4 | 5), RenderFunctions.cpp:80-85,96
+    // recipe P (config 5): the Monte-Carlo gather. A chain = one sample of one pixel (index as `pix` above);
+    // gi_h[(depth * 4 + j) * gi_total + chain], depth 0 (primary hit) .. 4: {p, z} {N, hit | front << 1 | (mtl + 1) << 2}
+    // {incoming ray dir, key} {uvw, -}; gi_res[kind * gi_total + chain]: Shade() of the ambient-light tree (0) and of
+    // the scene-light tree (1) at the depth just shaded
+    float4*      gi_h;
+    float4*      gi_res;
+    uint32_t     gi_depth, gi_total;
     // a batch of FRAMES of recipe W (rtu_render_frames_device): the same index space, one camera per frame
     uint32_t     frame_batch;       // 0: no
     BatchCam     cam[RTU_MAX_BATCH];
@@ -200,7 +209,14 @@ struct KernelArgs {
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine
 // bottom-up) on `stream`. Returns hipError_t as int.
-int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream);
+// mode: RTU_LAUNCH_ALL; recipe P: RTU_LAUNCH_CHAIN (trace the chain's ray of depth gi_depth, no shading),
+// RTU_LAUNCH_SHADE (the two Shade() trees of every chain hit of depth gi_depth)
+#define RTU_LAUNCH_ALL   0
+#define RTU_LAUNCH_CHAIN 1
+#define RTU_LAUNCH_SHADE 2
+#define RTU_GI_BOUNCES   4   // monteCarloBounces, RenderFunctions.cpp:31
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL);
+int rtu_launch_gi_final(const KernelArgs& args, hipStream_t stream);
 
 // recipe S: add one sample's image to the accumulators / write the mean
 int rtu_launch_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream);

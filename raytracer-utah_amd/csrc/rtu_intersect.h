@@ -988,6 +988,9 @@ __device__ __forceinline__ uint32_t child_key(uint32_t key, uint32_t slot) { ret
 #define RTU_DRAW_REFR1 0x10000u
 #define RTU_DRAW_REFR2 0x20000u
 #define RTU_DRAW_REFL  0x30000u
+#define RTU_DRAW_GATHER 0x40000u   // recipe P: the two numbers of SampleHemiSphereCosine
+#define RTU_SLOT_GATHER 3u         // child_key slot of the hit of the gather ray
+#define RTU_SLOT_AMBIENT_TREE 4u   // child_key slot of the Shade() tree lit by MonteCarlo()'s AmbientLight
 #define RTU_RAND_MAX_F 2147483648.0f                  // static_cast<float>(RAND_MAX)
 #define RTU_THETA_DIV  ((float)(2147483647 / (2 * 3.14159265358979323846)))  // static_cast<float>(RAND_MAX/(2 * M_PI))
 // The key of the Shade() call a frame stands for, and whether the frame is sampled at all.
@@ -1013,6 +1016,43 @@ __device__ __forceinline__ void portable_sincos(float t, float& sn, float& cs) {
     const double so = (k & 1) ? c : s, co = (k & 1) ? s : c;
     sn = (float)((k & 2) ? -so : so);
     cs = (float)((((k + 1) & 2) != 0) ? -co : co);
+}
+
+// acos of a float in [-1, 1] in binary64 with IEEE operations only (fdlibm's e_acos rational approximation),
+// rounded to float: the sequence of the oracle's portable_acos.
+__device__ __forceinline__ double acos_poly(double z) {
+    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
+                     z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+__device__ __forceinline__ float portable_acos(float xf) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    const double x = (double)xf;
+    const double ax = fabs(x);
+    double r;
+    if (ax >= 1.0) r = x > 0 ? 0.0 : pi;
+    else if (ax < 0.5) r = pio2_hi - (x - (pio2_lo - x * acos_poly(x * x)));
+    else if (x < 0) {
+        const double z = (1.0 + x) * 0.5, s = sqrt(z);
+        r = pi - 2.0 * (s + (acos_poly(z) * s - pio2_lo));
+    } else {
+        const double z = (1.0 - x) * 0.5, s = sqrt(z);
+        r = 2.0 * (s + acos_poly(z) * s);
+    }
+    return (float)r;
+}
+// SampleHemiSphereCosine(origin, normal, 1.0), RenderFunctions.cpp:320-337
+__device__ __forceinline__ f3 sample_hemisphere_cosine(f3 normal, uint32_t key) {
+    const float sampleX = (float)rand31(key, RTU_DRAW_GATHER) / RTU_RAND_MAX_F;        // :324
+    const float samplePhi = (float)rand31(key, RTU_DRAW_GATHER + 1u) / RTU_THETA_DIV;  // :325
+    const float sampleTheta = (float)(0.5 * (double)portable_acos(1 - 2 * sampleX));  // :326
+    const f3 v1 = norm3(cross3(normal, mk3(sampleX, sampleX, sampleX)));               // :329
+    const f3 v2 = norm3(cross3(v1, normal));                                           // :330
+    float st, ct, sp, cp;
+    portable_sincos(sampleTheta, st, ct);
+    portable_sincos(samplePhi, sp, cp);
+    return (normal * (1.0f * ct) + v1 * ((1.0f * st) * cp)) + v2 * ((1.0f * st) * sp);  // :332-334
 }
 
 // SampleSphere (RenderFunctions.cpp:282-301): a point of the cube [-radius, radius]^3, drawn again

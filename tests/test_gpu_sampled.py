@@ -161,3 +161,55 @@ def test_begin_render_sampled_dropin(pkg, orc, golden, tmp_path):
     job = pkg.host.rtu_begin_render(scene._h, img._h, devs, 1, None, None)
     assert pkg.host.rtu_render_wait(job) == pkg.RTU_ERR_STOCHASTIC
     pkg.host.rtu_render_job_free(job)
+
+
+# ---- recipe P (config 5): the Monte-Carlo gather ---------------------------------------------------------
+def render_paths_gpu(pkg, ctx, scene, W, H, spp, shard_count=1, coop=None):
+    ctx.upload(scene)
+    shards, frames = [], []
+    for r in range(shard_count):
+        fr = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=r, shard_count=shard_count, samples=spp, gather_bounces=4)
+        if coop is not None:
+            fr.coop_threshold = 1 if not coop else 1 << 30
+        buf, _ = ctx.render(fr)
+        shards.append(buf)
+        frames.append(fr)
+    return pkg.assemble(shards, frames, H)
+
+
+@pytest.mark.parametrize("tag,spp", [("p11_p2_120x68", 2), ("p13_p2_96x72", 2), ("p10_s4_160x120", 3), ("teapot1_s2_160x90", 5), ("p9_s3_160x120", 2)])
+def test_paths_vs_oracle(pkg, orc, ctx, golden, tag, spp):
+    """MonteCarlo() unrolled over the chain on the device against the recursive oracle, keyed streams: z bit-exact,
+    RGB within the bar (the chain multiplies up to five Shade() trees: linear RGB to 1e-3 of the value)."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    W, H = g.width, g.height
+    cpu, _ = orc.render_paths(scene, W, H, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=8)
+    gpu = render_paths_gpu(pkg, ctx, scene, W, H, spp)
+    assert np.array_equal(gpu[..., 3].view(np.uint32), cpu[..., 3].view(np.uint32)), "z differs"
+    g8, _, gz8 = orc.postprocess(gpu)
+    c8, _, cz8 = orc.postprocess(cpu)
+    assert np.array_equal(gz8, cz8)
+    d8 = np.abs(g8.astype(np.int32) - c8.astype(np.int32))
+    assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
+    d = np.abs(gpu[..., :3].astype(np.float64) - cpu[..., :3].astype(np.float64))
+    assert (d / np.maximum(np.abs(cpu[..., :3]), 1e-2)).max() < 1e-3
+    if tag == "p11_p2_120x68":
+        three = render_paths_gpu(pkg, ctx, scene, W, H, spp, shard_count=3)
+        assert np.array_equal(three.view(np.uint32), gpu.view(np.uint32)), "3 shards differ from one GPU"
+        for coop in (True, False):
+            again = render_paths_gpu(pkg, ctx, scene, W, H, spp, coop=coop)
+            assert np.array_equal(again.view(np.uint32), gpu.view(np.uint32)), "stage-2 form changes the image"
+
+
+def test_paths_argument_checks(pkg, ctx, golden):
+    g = golden("p11_p2_120x68")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    out = np.empty((16, 16, 4), np.float32)
+    fr = pkg.frame_setup(scene.desc.camera, 16, 16, samples=0, gather_bounces=4)
+    assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(fr), out.ctypes.data, None) == pkg.RTU_ERR_ARG
+    fr = pkg.frame_setup(scene.desc.camera, 16, 16, samples=2, gather_bounces=3)
+    assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(fr), out.ctypes.data, None) == pkg.RTU_ERR_ARG
+    fr = pkg.frame_setup(scene.desc.camera, 16, 16, samples=2, gather_bounces=4)
+    assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(fr), out.ctypes.data, None) == 0

@@ -45,7 +45,7 @@ def test_c_abi_exports_every_declared_symbol(pkg):
 
 
 def test_struct_layouts_match_the_headers(pkg):
-    assert ctypes.sizeof(pkg.RtuFrameDesc) == 108 and pkg.RtuFrameDesc.samples.offset == 28 and pkg.RtuFrameDesc.dof.offset == 104
+    assert ctypes.sizeof(pkg.RtuFrameDesc) == 112 and pkg.RtuFrameDesc.gather_bounces.offset == 108 and pkg.RtuFrameDesc.samples.offset == 28 and pkg.RtuFrameDesc.dof.offset == 104
     assert ctypes.sizeof(pkg.RtuStats) == 88
     assert ctypes.sizeof(pkg.RtuCamera) == 56
     assert ctypes.sizeof(pkg.RtuEnvColor) == 32

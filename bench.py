@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--samples", type=int, default=0,
                     help="diagnostic only: S >= 1 renders recipe S (S samples per pixel; soft shadows, glossy bounces, depth of field) — "
                          "needed for the tags under tests/golden/ whose meta.json says recipe S; not the headline workload")
+    ap.add_argument("--paths", action="store_true",
+                    help="diagnostic only, with --samples S: recipe P — recipe S plus the 4-bounce Monte-Carlo gather of config 5")
     ap.add_argument("--size", default="", help="diagnostic only: WxH instead of the tag's own resolution (no golden z check then)")
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning: ray-list length below which stage 2 is cooperative (0 = library default)")
     ap.add_argument("--allgather", action="store_true", help="N>1: all_gather the framebuffer to every rank instead of gathering it to rank 0")
@@ -99,7 +101,8 @@ def main():
     ctx = pkg.Context(local_rank)
     ctx.upload(scene)  # inputs resident in HBM before any timing
 
-    frame = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, max_bounce=args.max_bounce, samples=args.samples)
+    frame = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, max_bounce=args.max_bounce, samples=args.samples,
+                            gather_bounces=4 if args.paths else 0)
     frame.coop_threshold = args.coop_threshold
     rows = pkg.shard_rows(frame)
     max_rows = pkg.hip.rtu_shard_max_rows(H, world)
@@ -120,11 +123,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # -- untimed: ray / traversal counters of this shard (stats kernel variant) --------
+    # (recipe P has no counting variant: its rays are counted by the oracle, on the host, for rank 0's rows only at N = 1)
     sframe = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, collect_stats=True,
                              max_bounce=args.max_bounce, samples=args.samples)
     ctx.render_device(sframe, shard.data_ptr(), stream)
     torch.cuda.synchronize()
     st = ctx.stats()
+    if args.paths:
+        if world != 1:
+            raise SystemExit("--paths is a single-GPU diagnostic")
+        _, ost = g.load_oracle().render_paths(scene, W, H, args.samples, threads=16)
+        st = dict(st, **{k: ost[k] for k in ("primary_rays", "primary_hits", "secondary_rays", "shadow_rays", "node_tests", "mesh_entries",
+                                             "inner_visits", "leaf_visits", "leaf_elems", "tri_tests", "tri_accepts")})
     keys = sorted(st)
     tot = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=cdev)
     if dist:
@@ -226,7 +236,7 @@ def main():
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (WORKLOAD_NAME if args.tag == WORKLOAD_TAG else args.tag) + (" recipe S, %d samples per pixel" % args.samples if args.samples else ""),
+            "config": {"workload": (WORKLOAD_NAME if args.tag == WORKLOAD_TAG else args.tag) + (" recipe %s, %d samples per pixel" % ("P" if args.paths else "S", args.samples) if args.samples else ""),
                        "width": W, "height": H,
                        "rays_per_frame": rays_per_frame, "primary": total["primary_rays"],
                        "secondary": total["secondary_rays"], "shadow": total["shadow_rays"],
@@ -239,14 +249,14 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch)},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(g, scene, W, H, rays_per_frame, args.cpu_seconds, args.cpu_threads, args.samples)
+            out["cpu_baseline"] = cpu_baseline(g, scene, W, H, rays_per_frame, args.cpu_seconds, args.cpu_threads, args.samples, args.paths)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, max_threads, samples=0):
+def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, max_threads, samples=0, paths=False):
     """The CPU oracle (a port: bit-identical restatement of the reference's Trace/Shade,
     see oracle/rtu_oracle.cpp) on this box's host cores, same workload, whole frames
     repeated until ~budget_s of wall time has been spent."""
@@ -257,6 +267,8 @@ def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, max_threads, samples=
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, max_threads))
     render = (lambda threads: orc.render_samples(scene, W, H, samples, threads=threads)) if samples else (lambda threads: orc.render(scene, W, H, threads=threads))
+    if paths:
+        render = lambda threads: orc.render_paths(scene, W, H, samples, threads=threads)
     t0 = time.perf_counter()
     render(1)
     t1 = time.perf_counter() - t0

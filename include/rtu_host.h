@@ -93,6 +93,10 @@ RtuRenderJob* rtu_begin_render(const RtuScene* scene, RtuImage* img,
 RtuRenderJob* rtu_begin_render_sampled(const RtuScene* scene, RtuImage* img,
                                        const int* device_ids, int n_devices, int samples,
                                        const char* result_png, const char* zbuffer_png);
+/* HEAD's path-traced mode (config 5): the same plus the 4-bounce Monte-Carlo gather (RtuFrameDesc.gather_bounces = 4). */
+RtuRenderJob* rtu_begin_render_paths(const RtuScene* scene, RtuImage* img,
+                                     const int* device_ids, int n_devices, int samples,
+                                     const char* result_png, const char* zbuffer_png);
 void      rtu_stop_render(RtuRenderJob* job);      /* cooperative cancel between bands */
 int       rtu_render_wait(RtuRenderJob* job);      /* join; 0 or negative error code */
 void      rtu_render_job_free(RtuRenderJob* job);

@@ -159,7 +159,7 @@ HOST_SYMBOLS = ["rtu_scene_load_xml", "rtu_scene_clone", "rtu_scene_load_blob", 
                 "rtu_image_free", "rtu_image_width", "rtu_image_height", "rtu_image_pixels", "rtu_image_zbuffer",
                 "rtu_image_zimage", "rtu_image_num_rendered", "rtu_image_is_done", "rtu_image_from_rgbz",
                 "rtu_image_compute_zimg", "rtu_image_save_png", "rtu_image_save_zpng", "rtu_write_png",
-                "rtu_begin_render", "rtu_begin_render_sampled", "rtu_stop_render", "rtu_render_wait", "rtu_render_job_free"]
+                "rtu_begin_render", "rtu_begin_render_sampled", "rtu_begin_render_paths", "rtu_stop_render", "rtu_render_wait", "rtu_render_job_free"]
 _sig(host, "rtu_scene_load_xml", _P, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
 _sig(host, "rtu_scene_clone", _P, _P)
 _sig(host, "rtu_scene_load_blob", _P, _P, ctypes.c_size_t)
@@ -187,6 +187,7 @@ _sig(host, "rtu_image_save_zpng", _I, _P, ctypes.c_char_p)
 _sig(host, "rtu_write_png", _I, ctypes.c_char_p, _P, _I, _I, _I)
 _sig(host, "rtu_begin_render", _P, _P, _P, ctypes.POINTER(_I), _I, ctypes.c_char_p, ctypes.c_char_p)
 _sig(host, "rtu_begin_render_sampled", _P, _P, _P, ctypes.POINTER(_I), _I, _I, ctypes.c_char_p, ctypes.c_char_p)
+_sig(host, "rtu_begin_render_paths", _P, _P, _P, ctypes.POINTER(_I), _I, _I, ctypes.c_char_p, ctypes.c_char_p)
 _sig(host, "rtu_stop_render", None, _P)
 _sig(host, "rtu_render_wait", _I, _P)
 _sig(host, "rtu_render_job_free", None, _P)

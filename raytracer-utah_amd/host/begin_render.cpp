@@ -24,7 +24,7 @@ struct RtuRenderJob {
 
 namespace {
 
-void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::vector<int> devices, int samples,
+void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::vector<int> devices, int samples, int gather_bounces,
              std::string result_png, std::string zbuffer_png) {
     const int W = rtu_image_width(img), H = rtu_image_height(img);
     const int G = (int)devices.size();
@@ -49,6 +49,7 @@ void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::ve
         frames[g].shard_rank = g;
         frames[g].shard_count = G;
         frames[g].samples = samples;
+        frames[g].gather_bounces = gather_bounces;
         size_t bytes = (size_t)rtu_shard_rows(&frames[g]) * W * 4 * sizeof(float);
         if (bytes == 0) continue;
         dbuf[g] = rtu_device_alloc(ctxs[g], bytes);
@@ -92,17 +93,27 @@ void run_job(RtuRenderJob* job, const RtuSceneDesc* desc, RtuImage* img, std::ve
 
 extern "C" {
 
-RtuRenderJob* rtu_begin_render_sampled(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices, int samples,
-                                       const char* result_png, const char* zbuffer_png) {
+static RtuRenderJob* begin(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices, int samples, int gather_bounces,
+                           const char* result_png, const char* zbuffer_png) {
     if (!scene || !img || !device_ids || n_devices < 1 || samples < 0) {
         rtu::set_error("rtu_begin_render: bad arguments");
         return nullptr;
     }
     RtuRenderJob* job = new RtuRenderJob;
     std::vector<int> devs(device_ids, device_ids + n_devices);
-    job->thread = std::thread(run_job, job, rtu_scene_desc(scene), img, devs, samples, std::string(result_png ? result_png : ""),
+    job->thread = std::thread(run_job, job, rtu_scene_desc(scene), img, devs, samples, gather_bounces, std::string(result_png ? result_png : ""),
                               std::string(zbuffer_png ? zbuffer_png : ""));
     return job;  // returns immediately, as BeginRender() must
+}
+
+RtuRenderJob* rtu_begin_render_sampled(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices, int samples,
+                                       const char* result_png, const char* zbuffer_png) {
+    return begin(scene, img, device_ids, n_devices, samples, 0, result_png, zbuffer_png);
+}
+
+RtuRenderJob* rtu_begin_render_paths(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices, int samples,
+                                     const char* result_png, const char* zbuffer_png) {
+    return begin(scene, img, device_ids, n_devices, samples, 4, result_png, zbuffer_png);
 }
 
 RtuRenderJob* rtu_begin_render(const RtuScene* scene, RtuImage* img, const int* device_ids, int n_devices,

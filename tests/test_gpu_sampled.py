@@ -213,3 +213,25 @@ def test_paths_argument_checks(pkg, ctx, golden):
     assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(fr), out.ctypes.data, None) == pkg.RTU_ERR_ARG
     fr = pkg.frame_setup(scene.desc.camera, 16, 16, samples=2, gather_bounces=4)
     assert pkg.hip.rtu_render_frame(ctx._h, ctypes.byref(fr), out.ctypes.data, None) == 0
+
+
+def test_begin_render_paths_dropin(pkg, orc, golden, tmp_path):
+    """HEAD's BeginRender() renders the path-traced mode: the drop-in with the gather, PNGs against the oracle."""
+    from conftest import read_png
+    g = golden("p11_p2_120x68")
+    scene = g.scene(pkg)
+    spp = 3
+    cpu, _ = orc.render_paths(scene, g.width, g.height, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=8)
+    c8, _, cz8 = orc.postprocess(cpu)
+    img = pkg.Image(g.width, g.height)
+    devs = (ctypes.c_int * 1)(0)
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    job = pkg.host.rtu_begin_render_paths(scene._h, img._h, devs, 1, spp, rp.encode(), zp.encode())
+    assert job
+    assert pkg.host.rtu_render_wait(job) == 0, pkg.host.rtu_host_last_error()
+    pkg.host.rtu_render_job_free(job)
+    assert np.array_equal(read_png(zp), cz8)
+    png = read_png(rp)
+    if png.ndim == 2:
+        png = np.repeat(png[..., None], 3, axis=2)
+    assert np.abs(png.astype(np.int32) - c8.astype(np.int32)).max() <= RGB8_TOL

@@ -235,3 +235,22 @@ def test_portable_acos_within_one_ulp_of_libm(orc):
     la = np.array([libm.acosf(float(v)) for v in x[:20000]], np.float32)
     dd = np.abs(got[:20000].view(np.int32).astype(np.int64) - la.view(np.int32).astype(np.int64))
     assert dd.max() <= 1 and (dd != 0).mean() < 0.12  # glibc acosf is within 1 ulp, not correctly rounded
+
+
+def test_recipe_p_keyed_stream_is_the_same_estimator(pkg, orc, golden):
+    """Recipe P on the keyed streams (what the device follows) against the sequential ones (what the reference with
+    wrapped rand() follows): identical z, image means within the Monte-Carlo noise of 24 samples per pixel."""
+    g = golden("p11_p2_120x68")
+    scene = g.scene(pkg)
+    a, _ = orc.render_paths(scene, g.width, g.height, 24, stream=orc.STREAM_SEQUENTIAL, trig=orc.TRIG_LIBM, threads=8)
+    b, _ = orc.render_paths(scene, g.width, g.height, 24, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=8)
+    assert np.array_equal(a[..., 3].view(np.uint32), b[..., 3].view(np.uint32))
+    for c in range(3):
+        ma, mb = a[..., c].mean(), b[..., c].mean()
+        assert abs(ma - mb) < 0.02 * ma, (c, ma, mb)
+    # 8x8 block means agree too (no structured bias): relative L1 difference of the block images
+    def blocks(x):
+        h, w = x.shape[0] // 8 * 8, x.shape[1] // 8 * 8
+        return x[:h, :w, :3].reshape(h // 8, 8, w // 8, 8, 3).mean((1, 3))
+    ba, bb = blocks(a), blocks(b)
+    assert np.abs(ba - bb).sum() / np.abs(ba).sum() < 0.08

@@ -124,8 +124,11 @@ struct DevScene {
 
 struct LevelBuffers {
     float4* fa;      // {p.xyz, info}
-    float4* fb;      // {N.xyz, level 0: shard-local pixel index}
-    float4* fc;      // {ray dir.xyz, hInfo.z}
+    float4* fb;      // {N.xyz, w}: w = level 0: pixel index in the launch's [batch entry][pixel of the shard] space; deeper
+                     //   levels: the key of the frame's sample streams (recipe S / P) or its batch entry (frames in flight).
+                     //   Recipe P: the key at every level
+    float4* fc;      // {ray dir.xyz, w}: w = hInfo.z of the hit this frame shades (read at level 0 for the z output);
+                     //   recipe P: the chain the frame belongs to, at every level
     float4* fres;    // {Shade() result rgb, -}; holds the direct term until combined
     int4*   fchild;  // {main child, Fresnel child, mirror child, pending}
     float*  fsh;     // [cap * nsl] Shadow() of every non-ambient light

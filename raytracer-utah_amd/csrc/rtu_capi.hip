@@ -772,9 +772,9 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
     }
     int rounds = 0;
     for (int i = 0; i < frame->samples; i += batch) {
-        int nb;
-        for (; !gi;) {
-            nb = frame->samples - i < batch ? frame->samples - i : batch;
+        int nb = frame->samples - i < batch ? frame->samples - i : batch;
+        while (!gi) {
+            nb = frame->samples - i < batch ? frame->samples - i : batch;  // (i may have been reset below)
             int rc = launch(ctx, frame, ctx->sample_buf, stream, zero_counters && i == 0, i, nb);
             if (rc != RTU_OK) return rc;
             RTU_HIP(ctx, hipStreamSynchronize(stream));
@@ -787,7 +787,6 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
         if (gi) {
             // recipe P: the chain of gather rays first (depth 0 = the primary ray), then the Shade() trees from the
             // deepest hit up — each depth's AmbientLight needs the results of the depth below (k_gi_roots)
-            nb = frame->samples - i < batch ? frame->samples - i : batch;
             if (frame->collect_stats) return fail(ctx, RTU_ERR_ARG, "the counting variant does not cover recipe P");
             for (int k = 0; k <= RTU_GI_BOUNCES; k++) {
                 int rc = launch(ctx, frame, ctx->sample_buf, stream, false, i, nb, nullptr, RTU_LAUNCH_CHAIN, k);

@@ -56,6 +56,9 @@ def main():
                     help="diagnostic only, with --samples S: recipe P — recipe S plus the 4-bounce Monte-Carlo gather of config 5")
     ap.add_argument("--size", default="", help="diagnostic only: WxH instead of the tag's own resolution (no golden z check then)")
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning: ray-list length below which stage 2 is cooperative (0 = library default)")
+    ap.add_argument("--gather-float4", action="store_true",
+                    help="N>1: gather the float4 {r,g,b,z} shards (16 B per pixel) instead of the packed RenderImage content "
+                         "(float z + Color24, 7 B per pixel, converted on the device)")
     ap.add_argument("--allgather", action="store_true", help="N>1: all_gather the framebuffer to every rank instead of gathering it to rank 0")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 on a box with ONE GPU: every rank renders its shard on cuda:0 and the gather goes through gloo on host "
@@ -116,9 +119,17 @@ def main():
     # two shard / gather buffers: the RCCL gather of batch i runs while batch i+1 is rendered
     shards = [torch.zeros(B * max_rows * W * 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     root_only = not args.allgather
+    # N > 1: what travels to the root is the reference's RenderImage content — float z + Color24, 7 bytes per pixel,
+    # converted on the device (rtu_pack_image_device) — unless --gather-float4 asks for the raw float4 shards
+    packed = world > 1 and not args.gather_float4
+    pbytes = sharding.packed_bytes(B, max_rows, W)
+    sends = [torch.zeros(pbytes, dtype=torch.uint8, device=dev) for _ in range(2)] if packed else shards
     gathers = None
     if world > 1 and (rank == 0 or not root_only):
-        gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
+        if packed:
+            gathers = [torch.empty(world, pbytes, dtype=torch.uint8, device=cdev) for _ in range(2)]
+        else:
+            gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
     shard = shards[0]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -143,17 +154,21 @@ def main():
     rays_per_frame = pkg.total_rays(total)
     alg_bytes_launch = pkg.algorithmic_bytes(st, rows * W)  # this rank's launch
 
-    pipe = sharding.FramePipeline(shards, gathers, dist, staged=args.rehearse, root_only=root_only) if dist else None
+    pipe = sharding.FramePipeline(sends, gathers, dist, staged=args.rehearse, root_only=root_only) if dist else None
 
     def step(i, nb, ev=None):
         """One launch sequence: nb frames (steps) in flight."""
         buf = pipe.begin(i) if pipe else shard  # waits (on the GPU) for the gather that last read this buffer
+        if packed:
+            send, buf = buf, shards[i & 1]
         if ev:
             ev[0].record()
         if nb == 1:
             ctx.render_device(frame, buf.data_ptr(), stream)
         else:
             ctx.render_frames_device([frame] * nb, buf.data_ptr(), stream)
+        if packed:  # z of the nb frames, then their Color24 pixels (sharding.assemble_gathered_packed reads this layout)
+            ctx.pack_image_device(buf.data_ptr(), nb * rows * W, send.data_ptr(), send.data_ptr() + B * max_rows * W * 4, stream)
         if ev:
             ev[1].record()
         if pipe:
@@ -214,7 +229,12 @@ def main():
     if dist:
         if rank == 0:
             # the last frame of the last batch (frame j of rank r's chunk starts at j * rows_r * W float4)
-            img = sharding.assemble_gathered_batch(pkg, gathered.view(world, -1).cpu().numpy(), batches[-1] - 1, scene.desc.camera, W, H, world)
+            if packed:
+                zimg, rgb8 = sharding.assemble_gathered_packed(pkg, gathered.view(world, -1).cpu().numpy(), batches[-1] - 1, B, scene.desc.camera, W, H, world, max_rows)
+                img = np.zeros((H, W, 4), np.float32)
+                img[..., 3] = zimg
+            else:
+                img = sharding.assemble_gathered_batch(pkg, gathered.view(world, -1).cpu().numpy(), batches[-1] - 1, scene.desc.camera, W, H, world)
     else:
         j = batches[-1] - 1
         img = shard.view(-1)[j * rows * W * 4:(j + 1) * rows * W * 4].view(rows, W, 4).cpu().numpy()
@@ -241,7 +261,7 @@ def main():
                        "rays_per_frame": rays_per_frame, "primary": total["primary_rays"],
                        "secondary": total["secondary_rays"], "shadow": total["shadow_rays"],
                        "frames_in_flight": batches[0], "frame_latency_ms": round(kernel_ms, 4),
-                       "sharding": "interleaved 8-row bands, RCCL gather of the float4 framebuffer to rank 0, overlapped with the next frame" if world > 1 else "single GPU",
+                       "sharding": ("interleaved 8-row bands, RCCL gather of the %s to rank 0, overlapped with the next batch" % ("RenderImage content (float z + Color24, 7 B per pixel, packed on the device)" if packed else "float4 framebuffer")) if world > 1 else "single GPU",
                        "z_bit_exact_vs_reference_golden": bool(z_ok)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

@@ -139,6 +139,13 @@ int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d
 #define RTU_MAX_FRAMES_IN_FLIGHT 16
 int  rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_frames, void* d_rgbz, void* hip_stream);
 
+/* The content of the reference's RenderImage from a rendered float4 image, on the device: d_z[i] = z,
+ * d_rgb8[3 i ..] = Color24(pow(c, 1/2.2)) (RenderFunctions.cpp:152-160; binary64 pow, cyColor.h:226 clamp) —
+ * 7 bytes per pixel instead of 16, which is what a multi-GPU gather should move. Asynchronous on hip_stream.
+ * (The host path, rtu_image_from_rgbz, does the same with glibc's pow; the two agree except where the device
+ * library's pow rounds a value sitting on a byte boundary the other way: within the +-1 level bar.) */
+int  rtu_pack_image_device(RtuContext* ctx, const void* d_rgbz, size_t n_pixels, void* d_z, void* d_rgb8, void* hip_stream);
+
 /* Render into the context's own framebuffer and copy the shard to host memory
  * h_rgbz (rtu_shard_rows * width * 4 floats). Synchronous. stats may be NULL. */
 int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, RtuStats* stats);

@@ -121,7 +121,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -135,6 +135,7 @@ _sig(hip, "rtu_shard_max_rows", _I, _I, _I)
 _sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
 _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
 _sig(hip, "rtu_render_frames_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _I, _P, _P)
+_sig(hip, "rtu_pack_image_device", _I, _P, _P, ctypes.c_size_t, _P, _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
@@ -298,6 +299,10 @@ class Context:
         """Frames in flight: len(frames) frames of recipe W in one launch sequence, images consecutive at d_ptr."""
         arr = (RtuFrameDesc * len(frames))(*frames)
         self._check(hip.rtu_render_frames_device(self._h, arr, len(frames), d_ptr, stream))
+
+    def pack_image_device(self, d_rgbz, n_pixels, d_z, d_rgb8, stream=None):
+        """float4 image -> float z + Color24 pixels (the reference's RenderImage content), on the device."""
+        self._check(hip.rtu_pack_image_device(self._h, d_rgbz, n_pixels, d_z, d_rgb8, stream))
 
     def frame_status(self):
         """Synchronise; raises RtuError(RTU_ERR_CAPACITY) if the frame must be rendered again."""

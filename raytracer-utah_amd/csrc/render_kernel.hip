@@ -1286,6 +1286,32 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* acc, const uint32
 }
 }  // namespace
 
+// ---- RenderImage content on the device: Color24 pixels + float z (RenderFunctions.cpp:152-160, cyColor.h:226,245) ----
+namespace {
+__device__ __forceinline__ uint8_t float_to_byte(float r) {  // Color24(Color): Clamp(int(c * 255)), cvttss2si semantics
+    const float v = r * 255;
+    int i;
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) i = (int)0x80000000;
+    else i = (int)v;
+    return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+__global__ void __launch_bounds__(256) k_pack_image(const float4* rgbz, unsigned long long pixels, float* z_out, uint8_t* rgb_out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= pixels) return;
+    const float4 v = rgbz[i];
+    z_out[i] = v.w;
+    rgb_out[3 * i + 0] = float_to_byte((float)pow((double)v.x, 1 / 2.2));  // pow(c, 1/2.2) in binary64, as the reference
+    rgb_out[3 * i + 1] = float_to_byte((float)pow((double)v.y, 1 / 2.2));
+    rgb_out[3 * i + 2] = float_to_byte((float)pow((double)v.z, 1 / 2.2));
+}
+}  // namespace
+
+int rtu_launch_pack_image(const float4* rgbz, unsigned long long pixels, float* z_out, unsigned char* rgb_out, hipStream_t stream) {
+    if (pixels == 0) return (int)hipSuccess;
+    hipLaunchKernelGGL(k_pack_image, dim3((unsigned)((pixels + 255u) / 256u)), dim3(256), 0, stream, rgbz, pixels, z_out, (uint8_t*)rgb_out);
+    return (int)hipGetLastError();
+}
+
 int rtu_launch_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream) {
     hipLaunchKernelGGL(k_accumulate, dim3((pixels + 255u) / 256u), dim3(256), 0, stream, samples, batch, acc, hits, pixels, first ? 1 : 0);
     return (int)hipGetLastError();

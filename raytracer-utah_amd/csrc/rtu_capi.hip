@@ -1155,6 +1155,16 @@ int rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_
     return launch(ctx, &frames[0], (float4*)d_rgbz, (hipStream_t)hip_stream, true, 0, n_frames, frames);
 }
 
+int rtu_pack_image_device(RtuContext* ctx, const void* d_rgbz, size_t n_pixels, void* d_z, void* d_rgb8, void* hip_stream) {
+    if (!ctx) return RTU_ERR_ARG;
+    if (n_pixels == 0) return RTU_OK;
+    if (!d_rgbz || !d_z || !d_rgb8) return fail(ctx, RTU_ERR_ARG, "NULL buffer");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = (hipError_t)rtu_launch_pack_image((const float4*)d_rgbz, (unsigned long long)n_pixels, (float*)d_z, (unsigned char*)d_rgb8, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
 int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     if (!ctx || !stats) return RTU_ERR_ARG;
     RTU_HIP(ctx, hipSetDevice(ctx->device));

@@ -225,6 +225,9 @@ int rtu_launch_gi_final(const KernelArgs& args, hipStream_t stream);
 int rtu_launch_accumulate(const float4* samples, uint32_t batch, float4* acc, uint32_t* hits, uint32_t pixels, bool first, hipStream_t stream);
 int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uint32_t pixels, uint32_t samples, hipStream_t stream);
 
+// gamma + Color24 + z of a float4 image: the content of the reference's RenderImage
+int rtu_launch_pack_image(const float4* rgbz, unsigned long long pixels, float* z_out, unsigned char* rgb_out, hipStream_t stream);
+
 int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 

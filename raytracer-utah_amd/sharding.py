@@ -75,6 +75,30 @@ def assemble_gathered_batch(pkg, chunks_np, j, camera, width, height, world):
     return pkg.assemble(parts, frames, height)
 
 
+def packed_bytes(B, max_rows, width):
+    """Bytes of one rank's gather buffer for B frames in flight of packed images (float z + Color24)."""
+    return B * max_rows * width * 7
+
+
+def assemble_gathered_packed(pkg, chunks_u8, j, B, camera, width, height, world, max_rows):
+    """The multi-GPU gather moves the reference's RenderImage content, 7 bytes per pixel: rank r's chunk (uint8) holds
+    the float z of its shard of every frame of the batch (frame j at float offset j * rows_r * W) in its first
+    B * max_rows * W * 4 bytes, then the Color24 pixels (frame j at byte offset j * rows_r * W * 3).
+    Returns frame j as (z [H, W] float32, rgb8 [H, W, 3] uint8)."""
+    import numpy as np
+    z = np.empty((height, width), np.float32)
+    rgb = np.empty((height, width, 3), np.uint8)
+    zbytes = B * max_rows * width * 4
+    for r in range(world):
+        fr = pkg.frame_setup(camera, width, height, shard_rank=r, shard_count=world)
+        rows = pkg.shard_global_rows(fr)
+        n = len(rows) * width
+        c = np.ascontiguousarray(chunks_u8[r])
+        z[rows] = c[:zbytes].view(np.float32)[j * n:(j + 1) * n].reshape(len(rows), width)
+        rgb[rows] = c[zbytes + j * n * 3:zbytes + (j + 1) * n * 3].reshape(len(rows), width, 3)
+    return z, rgb
+
+
 def global_minmax_z(z_local, dist, torch):
     """z-image normalisation needs the frame-wide zmin/zmax (scene.h:596-601): a 2-float
     all-reduce when the frame is not gathered to one place."""

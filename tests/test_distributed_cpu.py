@@ -78,6 +78,27 @@ def _worker(rank, world, port, tag, out_dir):
         for j in range(B):
             fj = sharding.assemble_gathered_batch(pkg, pipe.last_gathered().numpy(), j, scene.desc.camera, W, H, world)
             np.save(os.path.join(out_dir, "batch%d.npy" % j), fj)
+    # what bench.py gathers by default: the packed RenderImage content (float z + Color24, 7 bytes per pixel), B frames
+    # in flight; the device's pack kernel is stood in for by the oracle's post-process (same arithmetic on the host)
+    rgb8, _, _ = orc.postprocess(buf[:len(rows)])
+    pb = sharding.packed_bytes(B, max_rows, W)
+    send = np.zeros(pb, np.uint8)
+    zview = send[:B * max_rows * W * 4].view(np.float32)
+    for j in range(B):
+        zview[j * len(rows) * W:(j + 1) * len(rows) * W] = buf[:len(rows), :, 3].reshape(-1) + (j == 2) * 7.0
+        o = B * max_rows * W * 4 + j * len(rows) * W * 3
+        send[o:o + len(rows) * W * 3] = rgb8.reshape(-1)
+    st = torch.from_numpy(send)
+    gp = [torch.empty(world, pb, dtype=torch.uint8), torch.empty(world, pb, dtype=torch.uint8)] if rank == 0 else None
+    pipe = sharding.FramePipeline([st, st.clone()], gp, dist, root_only=True)
+    pipe.begin(0)
+    pipe.gather(0)
+    pipe.drain()
+    if rank == 0:
+        for j in (0, 2):
+            zj, rj = sharding.assemble_gathered_packed(pkg, pipe.last_gathered().numpy(), j, B, scene.desc.camera, W, H, world, max_rows)
+            np.save(os.path.join(out_dir, "packz%d.npy" % j), zj)
+            np.save(os.path.join(out_dir, "packrgb%d.npy" % j), rj)
     lo, hi = sharding.global_minmax_z(shard.view(max_rows, W, 4)[:len(rows), :, 3], dist, torch)
     img = sharding.assemble_gathered(pkg, gathered.view(world, max_rows, W, 4).numpy(), scene.desc.camera, W, H, world)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
@@ -99,6 +120,10 @@ def test_sharded_gather_reassembles_the_frame(pkg, orc, golden, tmp_path, world)
         img = np.load(tmp_path / ("rank%d.npy" % r))
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "rank %d assembled a different frame" % r
         lo, hi = np.load(tmp_path / ("minmax%d.npy" % r))
+    ref8, _, _ = orc.postprocess(ref)
+    for j in (0, 2):
+        assert np.array_equal(np.load(tmp_path / ("packz%d.npy" % j)), ref[..., 3] + np.float32(7.0 if j == 2 else 0.0))
+        assert np.array_equal(np.load(tmp_path / ("packrgb%d.npy" % j)), ref8)
     for j in range(3):
         fj = np.load(tmp_path / ("batch%d.npy" % j))
         assert np.array_equal(fj, ref + np.float32(1000.0 if j == 1 else 0.0)), "frame %d of the gathered batch" % j

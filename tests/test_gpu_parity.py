@@ -582,3 +582,35 @@ def test_frames_in_flight_equal_single_frames(pkg, ctx, golden, tag, shards):
     arr = (pkg.RtuFrameDesc * 2)(s, s)
     assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG
     pkg.hip.rtu_device_free(ctx._h, d)
+
+
+def test_pack_image_matches_the_host_postprocess(pkg, orc, ctx, golden):
+    """rtu_pack_image_device (what a multi-GPU gather moves: float z + Color24) against the host post-process:
+    z identical, every 8-bit channel within one level (binary64 pow on both sides: equal in practice)."""
+    for tag in ("teapot2_240x135", "p4_240x135", "p7_200x150"):
+        g = golden(tag)
+        scene = g.scene(pkg)
+        ctx.upload(scene)
+        W, H = g.width, g.height
+        fr = pkg.frame_setup(scene.desc.camera, W, H)
+        n = W * H
+        d = pkg.hip.rtu_device_alloc(ctx._h, n * 16)
+        dz = pkg.hip.rtu_device_alloc(ctx._h, n * 4)
+        drgb = pkg.hip.rtu_device_alloc(ctx._h, n * 3)
+        ctx.render_device(fr, d)
+        ctx.pack_image_device(d, n, dz, drgb)
+        ctx.frame_status()
+        img = np.empty((H, W, 4), np.float32)
+        z = np.empty((H, W), np.float32)
+        rgb = np.empty((H, W, 3), np.uint8)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, img.ctypes.data, d, n * 16) == 0
+        assert pkg.hip.rtu_copy_to_host(ctx._h, z.ctypes.data, dz, n * 4) == 0
+        assert pkg.hip.rtu_copy_to_host(ctx._h, rgb.ctypes.data, drgb, n * 3) == 0
+        want8, _, _ = orc.postprocess(img)
+        assert np.array_equal(z.view(np.uint32), img[..., 3].view(np.uint32))
+        dd = np.abs(rgb.astype(np.int32) - want8.astype(np.int32))
+        assert dd.max() <= RGB8_TOL
+        print("%s: %d of %d channel values differ from the host's" % (tag, int((dd > 0).sum()), n * 3))
+        assert sha256(z) == g.meta["sha256_z_f32"]
+        for p_ in (d, dz, drgb):
+            pkg.hip.rtu_device_free(ctx._h, p_)

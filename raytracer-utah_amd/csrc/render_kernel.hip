@@ -1220,7 +1220,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     const dim3 block(64);
     // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
     // workgroups, so the deeper, usually sparse levels get smaller grids
-    const dim3 gridT(8192), gridN(8192), gridS(8192), gridF(2048), gridC(1024), gridCoop(512);
+    // (measured with 16 frames in flight: 32768 instead of 8192 workgroups for the one-lane-per-ray stage 2 and 4096
+    // instead of 2048 for k_consume balance the chunks better, -8 %; a single frame is unchanged)
+    const dim3 gridT(8192), gridN(32768), gridS(8192), gridF(4096), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
     if (mode == RTU_LAUNCH_SHADE) {

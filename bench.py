@@ -265,6 +265,8 @@ def main():
                        "z_bit_exact_vs_reference_golden": bool(z_ok)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "note": "achieved = algorithmic (touched, cache-agnostic) bytes of SURVEY 8d / launch duration: the working set is "
+                                 "L2-resident, so this may exceed the HBM peak; traffic = HBM bytes per launch from the PMC counters",
                          "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch)},
         }

@@ -134,18 +134,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # -- untimed: ray / traversal counters of this shard (stats kernel variant) --------
-    # (recipe P has no counting variant: its rays are counted by the oracle, on the host, for rank 0's rows only at N = 1)
     sframe = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=rank, shard_count=world, collect_stats=True,
-                             max_bounce=args.max_bounce, samples=args.samples)
+                             max_bounce=args.max_bounce, samples=args.samples, gather_bounces=4 if args.paths else 0)
+    if args.samples:  # settle the frame-record capacities first: the counting pass of a sampled frame does not re-provision
+        ctx.render_device(frame, shard.data_ptr(), stream)
+        torch.cuda.synchronize()
     ctx.render_device(sframe, shard.data_ptr(), stream)
     torch.cuda.synchronize()
     st = ctx.stats()
-    if args.paths:
-        if world != 1:
-            raise SystemExit("--paths is a single-GPU diagnostic")
-        _, ost = g.load_oracle().render_paths(scene, W, H, args.samples, threads=16)
-        st = dict(st, **{k: ost[k] for k in ("primary_rays", "primary_hits", "secondary_rays", "shadow_rays", "node_tests", "mesh_entries",
-                                             "inner_visits", "leaf_visits", "leaf_elems", "tri_tests", "tri_accepts")})
     keys = sorted(st)
     tot = torch.tensor([st[k] for k in keys], dtype=torch.int64, device=cdev)
     if dist:

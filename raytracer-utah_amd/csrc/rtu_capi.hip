@@ -787,9 +787,8 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
         if (gi) {
             // recipe P: the chain of gather rays first (depth 0 = the primary ray), then the Shade() trees from the
             // deepest hit up — each depth's AmbientLight needs the results of the depth below (k_gi_roots)
-            if (frame->collect_stats) return fail(ctx, RTU_ERR_ARG, "the counting variant does not cover recipe P");
             for (int k = 0; k <= RTU_GI_BOUNCES; k++) {
-                int rc = launch(ctx, frame, ctx->sample_buf, stream, false, i, nb, nullptr, RTU_LAUNCH_CHAIN, k);
+                int rc = launch(ctx, frame, ctx->sample_buf, stream, zero_counters && i == 0 && k == 0, i, nb, nullptr, RTU_LAUNCH_CHAIN, k);
                 if (rc != RTU_OK) return rc;
             }
             for (int k = RTU_GI_BOUNCES; k >= 0; k--) {
@@ -800,6 +799,7 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
                     bool overflow = false;
                     if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
                     if (!overflow) break;  // (a repeated step reads the same chain records and results of depth k + 1)
+                    if (frame->collect_stats) return fail(ctx, RTU_ERR_CAPACITY, "recipe P with counters: frame records ran out; render once without counters first");
                     if (++rounds > 8 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
                 }
             }

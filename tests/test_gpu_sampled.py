@@ -194,6 +194,12 @@ def test_paths_vs_oracle(pkg, orc, ctx, golden, tag, spp):
     assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
     d = np.abs(gpu[..., :3].astype(np.float64) - cpu[..., :3].astype(np.float64))
     assert (d / np.maximum(np.abs(cpu[..., :3]), 1e-2)).max() < 1e-3
+    # the counting variant: same image, traversal and ray counters equal to the oracle's (gather rays are in no ray counter)
+    _, cst = orc.render_paths(scene, W, H, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=8)
+    frs = pkg.frame_setup(scene.desc.camera, W, H, samples=spp, gather_bounces=4, collect_stats=True)
+    cnt, gst = ctx.render(frs, stats=True)
+    assert np.array_equal(cnt.view(np.uint32), gpu.view(np.uint32)), "fast and counting variants differ"
+    assert gst == cst, "counters differ"
     if tag == "p11_p2_120x68":
         three = render_paths_gpu(pkg, ctx, scene, W, H, spp, shard_count=3)
         assert np.array_equal(three.view(np.uint32), gpu.view(np.uint32)), "3 shards differ from one GPU"

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
     ap.add_argument("--frames-in-flight", type=int, default=-1,
                     help="frames rendered by one launch sequence (rtu_render_frames_device). Default: as many as keep 2^25 pixels in "
-                         "flight on a GPU, at most 16 (16 at 1080p). 1: one frame per launch "
+                         "flight on a GPU, at most 32 (16 full 1080p frames, 32 shards of a half frame or less). 1: one frame per launch "
                          "sequence — the frame LATENCY configuration")
     ap.add_argument("--samples", type=int, default=0,
                     help="diagnostic only: S >= 1 renders recipe S (S samples per pixel; soft shadows, glossy bounces, depth of field) — "
@@ -114,8 +114,8 @@ def main():
     if args.samples:
         B = 1  # recipe S batches its samples itself
     elif B < 1:
-        B = max(1, min(16, (1 << 25) // max(1, max_rows * W)))
-    B = max(1, min(B, 16, args.steps))
+        B = max(1, min(32, (1 << 25) // max(1, max_rows * W)))
+    B = max(1, min(B, 32, args.steps))
     # two shard / gather buffers: the RCCL gather of batch i runs while batch i+1 is rendered
     shards = [torch.zeros(B * max_rows * W * 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     root_only = not args.allgather

@@ -136,7 +136,7 @@ int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d
  * One 1080p frame at one sample per pixel is too little work to fill 256 CUs: sixteen in
  * flight render at 2.4 times the rays per second. Every frame is the image rtu_render_frame_device
  * gives for it, bit for bit. Asynchronous; rtu_frame_status afterwards as for a single frame. */
-#define RTU_MAX_FRAMES_IN_FLIGHT 16
+#define RTU_MAX_FRAMES_IN_FLIGHT 32
 int  rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_frames, void* d_rgbz, void* hip_stream);
 
 /* The content of the reference's RenderImage from a rendered float4 image, on the device: d_z[i] = z,

@@ -1151,7 +1151,7 @@ int rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_
     if (!d_rgbz) return fail(ctx, RTU_ERR_ARG, "d_rgbz is NULL");
     if (pixels * (size_t)n_frames > ((size_t)1 << 26)) return fail(ctx, RTU_ERR_ARG, "more than 2^26 pixels in flight");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
-    static_assert(RTU_MAX_FRAMES_IN_FLIGHT == RTU_MAX_BATCH, "batch size");
+    static_assert(RTU_MAX_FRAMES_IN_FLIGHT == RTU_MAX_FRAME_BATCH, "batch size");
     return launch(ctx, &frames[0], (float4*)d_rgbz, (hipStream_t)hip_stream, true, 0, n_frames, frames);
 }
 

@@ -573,11 +573,14 @@ def test_frames_in_flight_equal_single_frames(pkg, ctx, golden, tag, shards):
         pkg.hip.rtu_device_free(ctx._h, d)
     # errors: frames that differ in more than their cameras, too many frames, sampled frames
     a, b = pkg.frame_setup(scene.desc.camera, W, H), pkg.frame_setup(scene.desc.camera, W, H + 8)
-    d = pkg.hip.rtu_device_alloc(ctx._h, 20 * (H + 8) * W * 16)
+    d = pkg.hip.rtu_device_alloc(ctx._h, 36 * (H + 8) * W * 16)
     arr = (pkg.RtuFrameDesc * 2)(a, b)
     assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG
-    arr17 = (pkg.RtuFrameDesc * 17)(*([a] * 17))
-    assert pkg.hip.rtu_render_frames_device(ctx._h, arr17, 17, d, None) == pkg.RTU_ERR_ARG
+    arr33 = (pkg.RtuFrameDesc * 33)(*([a] * 33))
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr33, 33, d, None) == pkg.RTU_ERR_ARG
+    arr32 = (pkg.RtuFrameDesc * 32)(*([a] * 32))
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr32, 32, d, None) == 0
+    ctx.frame_status()
     s = pkg.frame_setup(scene.desc.camera, W, H, samples=2)
     arr = (pkg.RtuFrameDesc * 2)(s, s)
     assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG

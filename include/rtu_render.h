@@ -88,8 +88,9 @@ typedef struct RtuFrameDesc {
  * reflection, 2 mirror reflection) has child_key(key, slot) = mix32(key + (slot + 1) * 0x632be5ab).
  * purpose: 0, 1 lens sample (sampleX, sampleTheta); 16 + 2 l, 17 + 2 l light l's disk sample (sampleR,
  * sampleTheta); 0x10000 / 0x20000 / 0x30000 + 3 a + {0,1,2}: attempt a of SampleSphere for the first /
- * second refraction normal and for the reflection normal. sin and cos of sampleTheta are evaluated in
- * binary64 with IEEE operations only (oracle/rtu_oracle.cpp portable_sincos states the sequence). */
+ * second refraction normal and for the reflection normal. sin, cos (and, recipe P, acos) of the sampled
+ * angles are evaluated in binary64 with IEEE operations only and rounded to float (portable_sincos /
+ * portable_acos in raytracer-utah_amd/csrc/rtu_intersect.h state the sequences), within one ulp of libm's. */
 
 /* Ray and traversal counters of one frame (all shards of one context). Same
  * fields as RtuOracleStats so CPU and GPU can be compared exactly. */

@@ -1,1069 +1,13 @@
-// render_kernel.hip — the per-pixel render hot path as a LEVEL-SYNCHRONOUS WAVEFRONT
-// of hand-written gfx950 kernels. No MFMA: there is no dense contraction here.
-//
-// Why not one thread = one pixel for the whole recursion (round-1 v1 of this file):
-// rocprof showed the GPU ~95 % idle — a pixel on the glass sphere fires ~20 rays
-// ONE AFTER ANOTHER (depth-first Shade recursion), a wave is as slow as its slowest
-// lane, and a handful of such waves lasted as long as the whole launch
-// (profiles/r01_v1_*). The reference's recursion tree is therefore evaluated level
-// by level; everything that is independent runs in parallel across the chip:
-//
-//   k_primary      one 8x8 pixel tile per wavefront: primary ray -> closest hit; a miss
-//                  writes the pixel, a hit appends a level-0 "frame" (= one Shade() call)
-//   per level L = 0 .. max_bounce:
-//     k_trace(L)   one lane per (frame, ray slot): the shadow ray of every non-ambient
-//                  light, the refracted/TIR ray, the Fresnel ray, the mirror ray — slot-major,
-//                  so a wavefront traces 64 rays of the same kind for 64 neighbouring frames
-//     k_consume(L) one lane per frame: direct lighting in the reference's light order; hits
-//                  of secondary rays become frames of level L+1; a frame without children is final
-//   per level L = max_bounce-1 .. 0:
-//     k_combine(L) frames that wait for children combine them in the reference's exact term
-//                  order (mtlFunctions.cpp:205-291); level 0 writes the pixel
-//
-// What replaces what (reference file:line):
-//   tile/lane -> (x,y)     PixelIterator::GetPixelLocation          PixelIterator.h:25-38
-//   k_primary              Render(): ray set-up + Trace             RenderFunctions.cpp:96-103,258-268
-//   k_trace shadow slots   Light::Illuminate -> GenLight::Shadow    lightFunctions.cpp:27-84, lights.h:48
-//   k_trace secondary      MtlBlinn::Shade ray generation           mtlFunctions.cpp:160-229,239,273-283
-//   k_consume direct term  MtlBlinn::Shade light loop               mtlFunctions.cpp:125-155
-//   finalize()             MtlBlinn::Shade combination              mtlFunctions.cpp:205-291
-// The ray/scene arithmetic itself is in rtu_intersect.h.
-//
-// Exactness: a frame's arithmetic is the same sequence of float operations as the
-// recursive code; only the ORDER IN WHICH INDEPENDENT FRAMES ARE EVALUATED changes.
-// In the fast variant the Fresnel ray is traced speculatively alongside the
-// refracted ray (its result is used only if the refracted ray hit, :234-251); the
-// counting variant (collect_stats) traces it in a second pass so that its ray and
-// traversal counters equal the CPU oracle's.
+// render_kernel.hip — dispatch of a launch sequence to the feature set's translation unit
+// (render_feat*.hip, all instantiating render_impl.h) plus the small kernels that are not part
+// of a launch sequence: recipe S / P accumulation, the RenderImage packer, the self-tests.
 #include "rtu_intersect.h"
 
 namespace {
-
-// Feature mask of a kernel instantiation (template parameter TEX): bit 0 the scene is textured (uvw
-// carried, maps sampled), bit 1 the frame is sampled (recipe S: sample streams, soft shadows, glossy
-// bounces, lens). Recipe W on an untextured scene compiles to exactly the code it had before either existed.
-#define TEXD ((TEX & 1) != 0)
-#define SMPD ((TEX & 2) != 0)
-// bit 2: the launch renders a batch of FRAMES of recipe W (rtu_render_frames_device), each with its own
-// camera; its pixel index space is [frame in batch][pixel of the shard], like a batch of samples
-#define BATD ((TEX & 4) != 0)
-// bit 3: recipe P (with bit 1): the launches of the Monte-Carlo gather — chain tracing and the two Shade()
-// trees per chain hit, one of them lit by MonteCarlo()'s AmbientLight
-#define GID ((TEX & 8) != 0)
-
-enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
-// k_trace slot selection bits
-enum { SEL_SHADOW = 1, SEL_MAIN = 2, SEL_A = 4, SEL_C = 8, SEL_A_NEEDS_B = 16 };
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// GPU-clock timeline (rtu_render_timeline): when a.tl is set the first 64 workgroups store the
-// constant 100 MHz clock on entry and every wavefront stores it on exit (plain stores into
-// per-workgroup slots, no atomics); the host takes min / max per kernel. Unlike a profiler's
-// trace this does not serialise or pad the launches. kid: RTU_TL_* slot of the launch.
-struct Stamp {
-    unsigned long long* p;
-    __device__ __forceinline__ Stamp(const KernelArgs& a, int kid) : p(nullptr) {
-        if (a.tl) {
-            p = a.tl + (size_t)kid * RTU_TL_STRIDE;
-            if (blockIdx.x < 64u && threadIdx.x == 0) p[blockIdx.x] = (unsigned long long)wall_clock64();
-        }
-    }
-    __device__ __forceinline__ ~Stamp() {
-        if (p && lane_id() == 0) p[64u + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RTU_TL_ENDS - 1u))] = (unsigned long long)wall_clock64();
-    }
-};
-enum { RTU_TL_PRIMARY = 0, RTU_TL_PRIMARY2C = 1, RTU_TL_PRIMARY2 = 2, RTU_TL_LEVEL0 = 3 /* +4L: trace, trace2c, trace2, consume */,
-       RTU_TL_COMBINE0 = 3 + 4 * RTU_MAX_LEVELS };
-
-// Wave-aggregated append: every lane with `want` gets a unique index into the level's
-// frame arrays; one atomic per wavefront. Must be reached by all 64 lanes.
-__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
-    unsigned long long mask = __ballot(want);
-    uint32_t base = 0;
-    uint32_t leader = 0;
-    if (mask != 0) {
-        leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    }
-    base = __shfl(base, (int)leader);
-    unsigned long long below = mask & ((1ull << lane_id()) - 1ull);
-    return base + (uint32_t)__popcll(below);
-}
-
-// Largest shard population of level L (wave-uniform): lane i reads shard i's counter.
-__device__ __forceinline__ uint32_t level_max_count(const KernelArgs& a, int L) {
-    uint32_t v = a.fcnt->n_frames[L][lane_id() % RTU_SHARDS];
-    const uint32_t cap = a.lv[L].cap_s;
-    if (v > cap) v = cap;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t shard_count(const KernelArgs& a, int L, uint32_t shard) {
-    uint32_t v = a.fcnt->n_frames[L][shard];
-    const uint32_t cap = a.lv[L].cap_s;
-    return v > cap ? cap : v;
-}
-
-template <bool STATS>
-__device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counters& cnt) {
-    if (!STATS) return;
-    unsigned vals[11] = {cnt.prim, cnt.prim_hit, cnt.sec, cnt.shd, cnt.node, cnt.mesh,
-                         cnt.inner, cnt.leafv, cnt.leafe, cnt.tri, cnt.acc};
-#pragma unroll
-    for (int i = 0; i < 11; i++) {
-        unsigned v = vals[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane_id() == 0 && v) atomicAdd(&a.counters[i], (unsigned long long)v);
-    }
-}
-
-// Which rays will this Shade() call fire? Decided once, when the frame is created.
-template <int TEX>
-__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp, bool amb = false) {
-    const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
-    uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
-    if (amb) info |= RTU_FI_AMB;                                         // the light list is one AmbientLight: no shadow rays
-    else if (front && s.n_lights > 0) info |= RTU_FI_SH;                 // mtlFunctions.cpp:125
-    if (bounce > 0) {                                                   // :158
-        if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
-            info |= RTU_FI_MAIN;
-            Refr r = refraction_terms(dir, p, N, front, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
-            if (r.sinTheta2 > 1) info |= RTU_FI_TIR;                    // :205
-        }
-        if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw))) info |= RTU_FI_C;  // :273
-    }
-    return info;
-}
-
-__device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Init, scene.h:162
-    h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
-}
-
-// Direction of secondary ray `slot` of a frame (mtlFunctions.cpp:207, :229, :239, :280).
-__device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 p, f3 N, const RTU_CONST RtuMaterial& m, Smp smp) {
-    if (slot == SLOT_C) return reflect_dir(dir, sampled_normal(p, N, smp, smp.on ? m.reflection_glossiness : 0.0f, RTU_DRAW_REFL));
-    Refr t = refraction_terms(dir, p, N, (info & RTU_FI_FRONT) != 0, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
-    if (info & RTU_FI_TIR) return reflect_dir(dir, t.sn);    // :207, the first sample
-    if (slot == SLOT_A) return reflect_dir(dir, t.sn2);      // :239, the second sample shadows the first
-    return norm3((-t.sn2) * t.cosTheta2 + t.SVector * t.sinTheta2);  // :229
-}
-
-// Append a level-0 frame (a Shade() call at a primary or, recipe P, a chain hit) and its entries in the two
-// slot lists: three appends issued back to back, one wait for the wavefront instead of three. Wave-uniform
-// call; `want` says whether the lane has a frame. Returns the frame index or ~0u.
-template <int TEX>
-__device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, uint32_t shard, uint32_t info, f3 p, f3 N, uint32_t fbw, f3 dir,
-                                                float fcw, f3 uvw) {
-    const LevelBuffers& lv = a.lv[0];
-    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
-    const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
-    const unsigned long long mf = __ballot(want), mm = __ballot(wm), mc = __ballot(wc);
-    uint32_t bf = 0, bm = 0, bc = 0;
-    if (mf) {
-        const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
-        if ((threadIdx.x & 63u) == leader) {
-            bf = atomicAdd(&a.fcnt->n_frames[0][shard], (uint32_t)__popcll(mf));
-            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][shard], (uint32_t)__popcll(mm));
-            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][shard], (uint32_t)__popcll(mc));
-        }
-        bf = (uint32_t)__shfl((int)bf, (int)leader);
-        bm = (uint32_t)__shfl((int)bm, (int)leader);
-        bc = (uint32_t)__shfl((int)bc, (int)leader);
-    }
-    uint32_t idx = ~0u;
-    if (want) {
-        const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
-        if (fl < lv.cap_s) {  // level 0 is sized for every root of the launch (ensure_levels): always true
-            idx = fl + shard * lv.cap_s;
-            if (TEXD) lv.fuv[idx] = make_float4(uvw.x, uvw.y, uvw.z, 0.0f);
-            lv.fa[idx] = make_float4(p.x, p.y, p.z, __uint_as_float(info));
-            lv.fb[idx] = make_float4(N.x, N.y, N.z, __uint_as_float(fbw));
-            lv.fc[idx] = make_float4(dir.x, dir.y, dir.z, fcw);
-            if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
-            if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
-        } else {
-            a.fcnt->overflow = 1;
-        }
-    }
-    return idx;
-}
-
-// A sampled launch renders a.batch consecutive samples of the frame at once (longer ray lists fill the chip
-// better): its pixel index space is [sample in batch][pixel of the shard]. pix -> global x, y and the
-// sample's place in the batch.
-template <int TEX>
-__device__ __forceinline__ void pixel_of(const KernelArgs& a, uint32_t pix, int& x, int& y, uint32_t& sidx) {
-    sidx = 0;
-    uint32_t lp = pix;
-    if (SMPD || BATD) {
-        sidx = pix / a.batch_pixels;
-        lp = pix - sidx * a.batch_pixels;
-    }
-    const uint32_t ly = lp / (uint32_t)a.frame.width;
-    x = (int)(lp - ly * (uint32_t)a.frame.width);
-    y = (int)(((ly / RTU_BAND_ROWS) * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + ly % RTU_BAND_ROWS);
-}
-
-// The key of the sample streams of the Shade() call a frame stands for (recipe S): level 0 frames
-// carry their pixel in fb.w, deeper frames their key.
-template <int TEX>
-__device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) {
-    Smp smp;
-    smp.on = SMPD;
-    smp.key = 0;
-    if (smp.on) {
-        const uint32_t w = __float_as_uint(fbw);
-        if (L == 0 && !GID) {
-            int x, y;
-            uint32_t sidx;
-            pixel_of<TEX>(a, w, x, y, sidx);
-            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index + sidx);
-        } else {
-            smp.key = w;
-        }
-    }
-    return smp;
-}
-
-// ------------------------------------------------------------------------------------
-// TWO-STAGE PHASES. A ray that never enters a mesh's bounding box costs a few hundred
-// instructions; one that does walks a BVH (tens to hundreds of dependent steps) and a
-// wavefront is as slow as its slowest lane. So every tracing phase runs twice:
-//   stage 1 (wide): 64 rays per wavefront; the scene-graph walk is abandoned the moment a
-//           ray passes a mesh's bounding box and the ray id is appended to a defer list;
-//   stage 2 (narrow): the deferred rays, compacted, walk the whole scene including the
-//           BVH with only R rays per wavefront (R = 8..64 chosen from the list length), so
-//           a wavefront waits for the slowest of R rays instead of 64 and all of its lanes
-//           are inside the BVH loop together.
-// The counting variant (STATS) does everything in stage 1 so that every node test is
-// counted exactly once.
-
-// Append one ray id to the defer list of phase `ph` (sharded like the frame arrays).
-__device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t shard, bool want, uint32_t id) {
-    uint32_t idx = wave_append(&a.fcnt->n_defer[ph][shard], want);
-    if (want) {
-        if (idx < a.defer_cap_s) a.defer_list[(size_t)shard * a.defer_cap_s + idx] = id;
-        else a.fcnt->overflow = 1;
-    }
-}
-
-// Geometry of a stage-2 launch: rays per wavefront from the (largest shard of the) list.
-struct NarrowGeom {
-    uint32_t R, kmax, nmax, sum;
-};
-__device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
-    uint32_t v = a.fcnt->n_defer[ph][lane_id() % RTU_SHARDS];
-    if (v > a.defer_cap_s) v = a.defer_cap_s;
-    uint32_t sum = v;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off);
-        v = o > v ? o : v;
-        sum += (uint32_t)__shfl_xor((int)sum, off);
-    }
-    NarrowGeom g;
-    g.nmax = v;
-    g.sum = sum;
-    // enough wavefronts to fill 256 CUs several times over before widening them
-    // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
-    g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 120000) ? 64u : 8u;
-    g.kmax = (v + g.R - 1u) / g.R;
-    return g;
-}
-
-// ---- the primary ray of one pixel -------------------------------------------------------
-template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
-__device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t sidx, uint32_t pix, uint32_t shard,
-                                              uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
-                                              const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
-    const DevScene& s = a.scene;
-    bool want = false;
-    Hit h;
-    fresh_hit(h, RTU_BIGFLOAT);
-    Ray ray;
-    f3 cam_origin = ld3(a.frame.origin), cam_u = ld3(a.frame.u), cam_v = ld3(a.frame.v);
-    ray.p = ld3(a.frame.cam_pos);
-    if (BATD) {  // every frame of the batch has its own camera
-        const BatchCam& c = a.cam[sidx];
-        ray.p = ld3(c.pos);
-        cam_origin = ld3(c.origin);
-        cam_u = ld3(c.u);
-        cam_v = ld3(c.v);
-    }
-    ray.dir = mk3(0, 0, 0);
-    int mid = -1;
-    deferred = false;
-    Smp smp;
-    smp.on = SMPD;
-    smp.key = 0;
-    if (GID && a.gi_depth > 0) {
-        // recipe P, chain depth k > 0: the gather ray from the hit of depth k - 1 (RenderFunctions.cpp:556-565)
-        const size_t hb = (size_t)(a.gi_depth - 1u) * 4u * a.gi_total + pix;
-        float4 hA = make_float4(0, 0, 0, 0), hB = hA, hC = hA;
-        if (valid) { hA = a.gi_h[hb]; hB = a.gi_h[hb + a.gi_total]; hC = a.gi_h[hb + 2u * (size_t)a.gi_total]; }
-        const size_t ho = (size_t)a.gi_depth * 4u * a.gi_total + pix;
-        if (valid && !(__float_as_uint(hB.w) & 1u)) {  // the chain ended above: no hit at this depth either
-            if (leader) a.gi_h[ho + a.gi_total] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-            valid = false;
-        }
-        if (valid) {
-            const uint32_t pkey = __float_as_uint(hC.w);
-            const f3 sampleOffset = sample_hemisphere_cosine(mk3(hB.x, hB.y, hB.z), pkey);
-            ray.p = mk3(hA.x, hA.y, hA.z);
-            ray.dir = norm3(sampleOffset);  // :562
-            smp.key = child_key(pkey, RTU_SLOT_GATHER);
-            bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
-            if (!deferred && leader) {
-                const int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
-                a.gi_h[ho] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-                a.gi_h[ho + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2)));
-                a.gi_h[ho + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
-                if (TEXD) a.gi_h[ho + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
-            }
-        }
-        return;
-    }
-    if (valid) {
-        float ox = 0.5f, oy = 0.5f;  // recipe W: the pixel centre
-        if (smp.on) {
-            // recipe S: RenderFunctions.cpp:80-97 — Halton offsets, a point of the lens disk
-            smp.key = sample_key((uint32_t)x + (uint32_t)a.frame.width * (uint32_t)y, a.sample_index + sidx);
-            ox = a.pix_off_x[sidx];
-            oy = a.pix_off_y[sidx];
-            const float sampleX = (float)rand31(smp.key, RTU_DRAW_LENS) / RTU_RAND_MAX_F;          // :88
-            const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LENS + 1u) / RTU_THETA_DIV;  // :89
-            float sn, cs;
-            portable_sincos(sampleTheta, sn, cs);
-            const float rad = sqrtf((sampleX * a.frame.dof) * a.frame.dof);
-            const float camOffsetX = rad * cs, camOffsetY = rad * sn;                               // :90-91
-            ray.p = (ray.p + ld3(a.frame.lens_up) * camOffsetY) + ld3(a.frame.lens_right) * camOffsetX;  // :93
-        }
-        // RenderFunctions.cpp:258-268, :97
-        f3 cp = (cam_origin + cam_u * ((float)x + ox)) + cam_v * ((float)y + oy);
-        ray.dir = norm3(cp - ray.p);
-        RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
-        if (!deferred && leader) {
-            if (!hit) {
-                f3 bg = background_sample<TEXD>(s, x, y);  // :145
-                a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
-            } else {
-                RTU_CNT(prim_hit);
-                mid = as_const(s.nodes)[h.node].material_id;
-                if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
-                else want = true;
-            }
-            if (GID) {  // recipe P: the chain's depth-0 record instead of a frame; a null material stays white
-                a.gi_h[pix] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-                a.gi_h[pix + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((want ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(mid + 1) << 2)));
-                a.gi_h[pix + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
-                if (TEXD) a.gi_h[pix + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
-                want = false;
-            }
-        }
-    }
-    if (GID) return;
-    uint32_t info = 0;
-    if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
-    append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw);
-}
-
-// stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
-template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
-    const Stamp stamp(a, RTU_TL_PRIMARY);
-    __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
-    uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t btile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (btile >= n_tiles) return;  // whole wavefront
-    const uint32_t sidx = (SMPD || BATD) ? btile / a.tiles_per_image : 0u;  // batched launches: n_tiles = batch x tiles of the image
-    const uint32_t tile = btile - sidx * a.tiles_per_image;
-    const uint32_t band_local = tile / a.tiles_x;
-    const uint32_t tx = tile - band_local * a.tiles_x;
-    const int x = (int)(tx * 8 + (lane & 7));
-    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
-    const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
-    const bool valid = x < a.frame.width && y < a.frame.height;
-    const uint32_t pix = ((SMPD || BATD) ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
-    const uint32_t shard = btile % RTU_SHARDS;
-    Counters cnt = {};
-    bool deferred;
-    primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
-    if (!STATS) defer_push(a, 0, shard, deferred, pix);
-    flush_counters<STATS>(a, cnt);
-}
-
-// Stage the top of every mesh's 8-wide tree (BFS order) into the workgroup's LDS node area.
-__device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nodes) {
-    const RTU_CONST DevMesh* meshes = as_const(a.scene.meshes);
-    for (uint32_t m = 0; m < a.n_meshes; m++) {
-        const float4* src = meshes[m].bvh8;
-        const uint32_t n = meshes[m].lds_nodes * 16u, off = meshes[m].lds_off;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_nodes[off + i] = src[i];
-    }
-    __syncthreads();
-}
-
-// stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
-template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
-    const Stamp stamp(a, RTU_TL_PRIMARY2);
-    __shared__ uint32_t s_stack[STACK * 64];
-    const uint32_t lane = threadIdx.x;
-    const NarrowGeom g = narrow_geom(a, 0);
-    if (g.R == 8u) return;  // short list: k_primary2c takes it
-    const uint32_t kmax = (g.nmax + 63u) / 64u;
-    const uint32_t chunks = kmax * RTU_SHARDS;
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][shard];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * 64u + lane;
-        const bool valid = e < ns;
-        uint32_t pix = 0;
-        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        int x, y;
-        uint32_t sidx;
-        pixel_of<TEX>(a, pix, x, y, sidx);
-        bool deferred;
-        primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + lane, cnt, deferred);
-    }
-}
-
-// stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
-// (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
-template <int STACK, int TEX>
-__global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
-    const Stamp stamp(a, RTU_TL_PRIMARY2C);
-    __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
-    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
-    const NarrowGeom g = narrow_geom(a, 0);
-    if (g.R != 8u) return;
-    const uint32_t grp = threadIdx.x >> 3;
-    const bool leader = (threadIdx.x & 7u) == 0;
-    // A very short list is pure latency: one wavefront per SIMD (32 rays per workgroup) so that
-    // the walks do not share VALU issue slots; longer lists use all 16 wavefronts.
-    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;
-    const uint32_t kmax = (g.nmax + groups - 1u) / groups;
-    const uint32_t chunks = kmax * RTU_SHARDS;
-    if (blockIdx.x >= chunks) return;  // nothing for this workgroup: do not stage the tree
-    stage_nodes(a, s_nodes);
-    if (grp >= groups) return;
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][shard];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * groups + grp;
-        const bool valid = e < ns;
-        uint32_t pix = 0;
-        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        int x, y;
-        uint32_t sidx;
-        pixel_of<TEX>(a, pix, x, y, sidx);
-        bool deferred;
-        primary_pixel<RTU_STACK8, false, false, true, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
-    }
-}
-
-// ---- one ray of one frame ------------------------------------------------------------------
-// slot < nsl: shadow ray of non-ambient light `slot`; else secondary ray slot - nsl.
-// Returns true if the ray was deferred (DEFER only).
-template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
-__device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, uint32_t slot, uint32_t f, uint32_t* stk, Counters& cnt,
-                                          bool leader = true, const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
-    const DevScene& s = a.scene;
-    const LevelBuffers& lv = a.lv[L];
-    const float4 fa = lv.fa[f];
-    const uint32_t info = __float_as_uint(fa.w);
-    const f3 p = mk3(fa.x, fa.y, fa.z);
-    Ray r;
-    r.p = p;
-    float tmax = RTU_BIGFLOAT;
-    const bool is_shadow = slot < a.nsl;
-    const int sslot = (int)slot - (int)a.nsl;
-    if (is_shadow) {
-        // ---- shadow ray (lightFunctions.cpp:27-37, 43-65, 75-78; lights.h:48)
-        if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) return false;
-        const int li = a.shadow_light[slot];
-        const RTU_CONST RtuLight& l = as_const(s.lights)[li];
-        f3 lvec = ld3(l.vec);
-        if (l.type == RTU_LIGHT_DIRECT) {
-            r.dir = -lvec;
-        } else if (SMPD && l.size > 0) {
-            // soft shadow: one ray towards a random point of the light's disk
-            const Smp smp = frame_smp<TEX>(a, L, lv.fb[f].w);
-            const float sampleR = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li) / (RTU_RAND_MAX_F / l.size);  // :47
-            const float sampleTheta = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li + 1u) / RTU_THETA_DIV;     // :48
-            float sn, cs;
-            portable_sincos(sampleTheta, sn, cs);
-            const float offsetX = sampleR * cs, offsetY = sampleR * sn;         // :49-50
-            const f3 samplePlaneNormal = norm3(lvec - p);                      // :52
-            const f3 v1 = norm3(cross3(samplePlaneNormal, mk3(0, 0, 1)));      // :55
-            const f3 v2 = norm3(cross3(v1, samplePlaneNormal));                // :56
-            const f3 currentSamplePos = (lvec + v1 * offsetX) + v2 * offsetY;  // :58
-            r.dir = norm3(currentSamplePos - p);                               // :60
-            tmax = len3(p - currentSamplePos);                                 // :62
-        } else {
-            r.dir = norm3(lvec - p);
-            tmax = len3(lvec - p);
-        }
-        RTU_CNT(shd);
-    } else {
-        // ---- secondary rays of MtlBlinn::Shade (mtlFunctions.cpp:160-229, 239, 273-283)
-        if (sslot == SLOT_MAIN && (!(sel & SEL_MAIN) || !(info & RTU_FI_MAIN))) return false;
-        if (sslot == SLOT_A && (!(sel & SEL_A) || !(info & RTU_FI_MAIN) || (info & RTU_FI_TIR))) return false;
-        if (sslot == SLOT_C && (!(sel & SEL_C) || !(info & RTU_FI_C))) return false;
-        if (sslot == SLOT_A && (sel & SEL_A_NEEDS_B)) {
-            // counting variant: the Fresnel ray exists only if the refracted ray hit (:234)
-            const float4 b1 = lv.fslot[((size_t)f * 3 + SLOT_MAIN) * 2 + 1];
-            if (!(__float_as_uint(b1.w) & 1u)) return false;
-        }
-        const float4 fb = lv.fb[f], fc = lv.fc[f];
-        const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-        r.dir = secondary_dir(sslot, info, dir, p, N, as_const(s.materials)[info & RTU_FI_MTL_MASK], frame_smp<TEX>(a, L, fb.w));
-        RTU_CNT(sec);
-    }
-    Hit h;
-    fresh_hit(h, tmax);
-    bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
-    if (DEFER && deferred) return true;
-    if (!leader) return false;
-    if (is_shadow) {
-        lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
-    } else {
-        int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
-        // packed: bit0 hit, bit1 front, bits 2.. material id + 1 (0 = node without material)
-        uint32_t packed = (hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2);
-        float4* slotp = lv.fslot + ((size_t)f * 3 + sslot) * 2;
-        slotp[0] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
-        slotp[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(packed));
-        if (TEXD) lv.fsuv[(size_t)f * 3 + sslot] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
-    }
-    return false;
-}
-
-// stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
-template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
-    __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
-    const LevelBuffers& lv = a.lv[L];
-    const uint32_t lane = threadIdx.x;
-    // shadow slots: every frame of the level; secondary slots: the frames listed for them (list_frame)
-    uint32_t vm = a.fcnt->n_lmain[L][lane % RTU_SHARDS], vc = a.fcnt->n_lrefl[L][lane % RTU_SHARDS];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)vm, off);
-        vm = o > vm ? o : vm;
-        o = (uint32_t)__shfl_xor((int)vc, off);
-        vc = o > vc ? o : vc;
-    }
-    const uint32_t chA = ((level_max_count(a, L) + 63u) / 64u) * RTU_SHARDS;  // 64-frame chunks, all shards
-    const uint32_t chM = ((vm + 63u) / 64u) * RTU_SHARDS, chC = ((vc + 63u) / 64u) * RTU_SHARDS;
-    const uint32_t total = a.nsl * chA + 2u * chM + chC;
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
-        uint32_t slot, cc;
-        const uint32_t* list = nullptr;
-        const uint32_t* counts = a.fcnt->n_frames[L];
-        if (c < a.nsl * chA) {
-            slot = c / chA;
-            cc = c - slot * chA;
-        } else if (c - a.nsl * chA < 2u * chM) {
-            const uint32_t c2 = c - a.nsl * chA;
-            slot = a.nsl + (c2 >= chM ? (uint32_t)SLOT_A : (uint32_t)SLOT_MAIN);
-            cc = c2 >= chM ? c2 - chM : c2;
-            list = lv.lmain;
-            counts = a.fcnt->n_lmain[L];
-        } else {
-            slot = a.nsl + (uint32_t)SLOT_C;
-            cc = c - a.nsl * chA - 2u * chM;
-            list = lv.lrefl;
-            counts = a.fcnt->n_lrefl[L];
-        }
-        const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
-        const uint32_t e = k * 64u + lane;
-        uint32_t ns = counts[shard];
-        if (ns > lv.cap_s) ns = lv.cap_s;
-        const bool active = e < ns;
-        const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
-        const uint32_t f = shard * lv.cap_s + fl;
-        bool deferred = false;
-        if (active) deferred = frame_ray<STACK, STATS, !STATS, false, TEX>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
-        if (!STATS) defer_push(a, ph, shard, deferred, (slot << 28) | f);
-    }
-    flush_counters<STATS>(a, cnt);
-}
-
-// stage 2, long lists: one lane per deferred ray
-template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
-    __shared__ uint32_t s_stack[STACK * 64];
-    const uint32_t lane = threadIdx.x;
-    const NarrowGeom g = narrow_geom(a, ph);
-    if (g.R == 8u) return;  // short list: k_trace2c takes it
-    const uint32_t kmax = (g.nmax + 63u) / 64u;
-    const uint32_t chunks = kmax * RTU_SHARDS;
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][shard];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * 64u + lane;
-        if (e >= ns) continue;
-        const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<STACK, false, false, false, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
-    }
-}
-
-// stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
-template <int STACK, int TEX>
-__global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
-    __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
-    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
-    const NarrowGeom g = narrow_geom(a, ph);
-    if (g.R != 8u) return;
-    const uint32_t grp = threadIdx.x >> 3;
-    const bool leader = (threadIdx.x & 7u) == 0;
-    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;  // see k_primary2c
-    const uint32_t kmax = (g.nmax + groups - 1u) / groups;
-    const uint32_t chunks = kmax * RTU_SHARDS;
-    if (blockIdx.x >= chunks) return;
-    stage_nodes(a, s_nodes);
-    if (grp >= groups) return;
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][shard];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
-        const uint32_t e = k * groups + grp;
-        if (e >= ns) continue;
-        const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
-        frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// MtlBlinn::Shade combination (mtlFunctions.cpp:205-291) once every child result is
-// known. st* >= 0 or RTU_CH_WHITE: that ray hit and ret* holds Shade() of the hit.
-template <int TEX>
-__device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMaterial& m, uint32_t info, f3 direct, f3 dir, f3 p,
-                                       f3 N, int stMain, int stA, int stC, f3 retMain, f3 retA, f3 retC, float bz, bool bfront, f3 uvw,
-                                       Smp smp) {
-    const bool front = (info & RTU_FI_FRONT) != 0;
-    const int mtl = (int)(info & RTU_FI_MTL_MASK);
-    // environment.SampleEnvironment(direction of the ray that missed); a constant without an environment map
-    auto env_at = [&](int slot) {
-        return (TEXD && s.env.has_map) ? env_sample(s, secondary_dir(slot, info, dir, p, N, m, smp)) : ld3(s.environment);
-    };
-    f3 result = direct;
-    if (info & RTU_FI_MAIN) {
-        const f3 refraction = mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw), absorption = ld3(m.absorption);
-        const bool mainHit = stMain >= 0 || stMain == RTU_CH_WHITE;
-        if (info & RTU_FI_TIR) {
-            if (mainHit) result = result + absorb(RTU_BIGFLOAT, absorption) * retMain;  // :210-221 (z of a fresh HitInfo)
-        } else if (mainHit) {
-            Refr r = refraction_terms(dir, p, N, front, m.ior, smp, smp.on ? m.refraction_glossiness : 0.0f);
-            float S = schlick(r);                                                        // :236-237
-            f3 absorptionV = mk3(1, 1, 1);
-            if (!bfront) absorptionV = absorb(bz, absorption);                           // :258-262
-            f3 term1 = ((absorptionV * refraction) * retMain) * (float)(1.0 - (double)S);
-            const bool aHit = stA >= 0 || stA == RTU_CH_WHITE;
-            f3 frenselResult = aHit ? refraction * retA : env_at(SLOT_A);  // :247 / :250
-            result = result + (term1 + frenselResult * S);                               // :264
-        } else {
-            result = result + env_at(SLOT_MAIN);  // :267
-        }
-    }
-    if (info & RTU_FI_C) {
-        const bool cHit = stC >= 0 || stC == RTU_CH_WHITE;
-        if (cHit) result = result + mtl_color<TEXD>(s, mtl, RTU_MAP_REFLECTION, ld3(m.reflection), uvw) * retC;  // :286
-        else result = result + env_at(SLOT_C) * ld3(m.reflection);  // :289: GetColor()
-    }
-    return result;
-}
-
-// One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
-// lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
-// a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
-template <bool STATS, int TEX>
-__device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
-                                              uint32_t f, int st_out[3]) {
-    const DevScene& s = a.scene;
-    const LevelBuffers& lv = a.lv[L];
-    const bool haveNext = L + 1 < RTU_MAX_LEVELS;
-    const int Ln = haveNext ? L + 1 : L;
-    const LevelBuffers& nx = a.lv[Ln];
-    f3 cam_pos = ld3(a.frame.cam_pos);
-    st_out[0] = st_out[1] = st_out[2] = RTU_CH_NONE;
-    float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
-    if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
-    const uint32_t info = __float_as_uint(fa.w);
-    const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-    const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
-    const int bounce = (int)((info >> RTU_FI_BOUNCE_SH) & 7u);
-    const Smp smp = frame_smp<TEX>(a, L, fb.w);
-    uint32_t entry = 0;  // batched frames: which frame of the batch this Shade() belongs to (its camera, :137)
-    if (BATD) {
-        entry = __float_as_uint(fb.w);
-        if (L == 0) entry /= a.batch_pixels;
-        if (entry >= a.batch) entry = 0;  // inactive lanes
-        cam_pos = ld3(a.cam[entry].pos);
-    }
-    f3 uvw = mk3(0, 0, 0);  // hInfo.uvw, textured scenes only
-    if (TEXD && active) {
-        const float4 t = lv.fuv[f];
-        uvw = mk3(t.x, t.y, t.z);
-    }
-
-    // ---- direct lighting, mtlFunctions.cpp:125-155, in light-list order ----
-    f3 direct = mk3(0, 0, 0);
-    f3 ambI = mk3(0, 0, 0);
-    if (GID && active && (info & RTU_FI_AMB)) {
-        // the light list is MonteCarlo()'s one AmbientLight: result += diffuse * intensity on front faces (:125-132)
-        const float4 t = lv.famb[f];
-        ambI = mk3(t.x, t.y, t.z);
-        if (info & RTU_FI_FRONT) direct = direct + mtl_color<TEXD>(s, (int)(info & RTU_FI_MTL_MASK), RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw) * ambI;
-    }
-    if (active && (info & RTU_FI_SH)) {
-        const int mtl = (int)(info & RTU_FI_MTL_MASK);
-        const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
-        const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
-        uint32_t j = 0;  // index among the non-ambient lights
-        const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
-        for (uint32_t i = 0; i < s.n_lights; i++) {
-            const RTU_CONST RtuLight& l = as_const(s.lights)[i];
-            const f3 intensity = ld3(l.intensity);
-            if (l.type == RTU_LIGHT_AMBIENT) {
-                direct = direct + diffuse * intensity;  // :132
-                continue;
-            }
-            const f3 lvec = ld3(l.vec);
-            const bool isDirect = l.type == RTU_LIGHT_DIRECT;
-            const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
-            const f3 lightDirection = norm3(-ldir);                       // :138
-            const f3 halfVector = norm3(viewDirection + lightDirection);  // :139
-            float NDotL = dot3(N, lightDirection);
-            float NDotH = dot3(N, halfVector);
-            if (NDotL < 0.0f) NDotL = 0.0f;
-            if (NDotH < 0.0f) NDotH = 0.0f;
-            const float sh = lv.fsh[(size_t)f * a.nsl + j];
-            j++;
-            f3 illum;
-            if (isDirect) {
-                illum = intensity * sh;  // lights.h:48
-            } else {
-                const f3 d = lvec - p;
-                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
-            }
-            direct = direct + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
-        }
-    }
-
-    // ---- secondary-ray hits become frames of the next level ----
-    // Every append below is one atomic per wavefront whose result the wavefront has to wait for,
-    // so they are batched: ONE append for the child frames of all three slots, then the appends to
-    // the slot lists and the pending list together (three round trips to L2 instead of ten).
-    int st[3] = {RTU_CH_NONE, RTU_CH_NONE, RTU_CH_NONE};
-    float bz = 0.0f;
-    bool bfront = true;
-    float4 s0[3], s1[3];
-    uint32_t packed[3];
-    bool spawn[3], slotAct[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        bool slotActive = false;
-        if (active) {
-            if (k == SLOT_MAIN) slotActive = (info & RTU_FI_MAIN) != 0;
-            else if (k == SLOT_A) slotActive = (info & RTU_FI_MAIN) && !(info & RTU_FI_TIR) && (packed[SLOT_MAIN] & 1u);  // :234: the refracted ray hit
-            else slotActive = (info & RTU_FI_C) != 0;
-        }
-        s0[k] = make_float4(0, 0, 0, 0);
-        s1[k] = s0[k];
-        packed[k] = 0;
-        if (slotActive) {
-            const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
-            s0[k] = slotp[0];
-            s1[k] = slotp[1];
-            packed[k] = __float_as_uint(s1[k].w);
-        }
-        slotAct[k] = slotActive;
-        const bool hit = slotActive && (packed[k] & 1u);
-        spawn[k] = hit && (int)(packed[k] >> 2) - 1 >= 0 && haveNext;
-        if (k == SLOT_MAIN && hit) { bz = s0[k].w; bfront = (packed[k] & 2u) != 0; }
-    }
-    // child frame indices: slot 0's children of the wavefront, then slot 1's, then slot 2's
-    uint32_t cfl[3];
-    {
-        const unsigned long long m0 = __ballot(spawn[0]), m1 = __ballot(spawn[1]), m2 = __ballot(spawn[2]);
-        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-        uint32_t base = 0;
-        if (n0 + n1 + n2) {
-            if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][cshard], n0 + n1 + n2);
-            base = (uint32_t)__shfl((int)base, 0);
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        cfl[0] = base + (uint32_t)__popcll(m0 & below);
-        cfl[1] = base + n0 + (uint32_t)__popcll(m1 & below);
-        cfl[2] = base + n0 + n1 + (uint32_t)__popcll(m2 & below);
-    }
-    bool wantMain[3] = {false, false, false}, wantRefl[3] = {false, false, false};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (!slotAct[k]) continue;
-        const bool hit = (packed[k] & 1u) != 0;
-        const int cmid = (int)(packed[k] >> 2) - 1;
-        if (!hit) st[k] = RTU_CH_MISS;
-        else if (cmid < 0) st[k] = RTU_CH_WHITE;
-        else if (spawn[k] && cfl[k] < nx.cap_s) {
-            const uint32_t idx = cfl[k] + cshard * nx.cap_s;
-            // the child Shade(): ray direction, hit point and normal of the secondary ray
-            const f3 cdir = secondary_dir(k, info, dir, p, N, m, smp);
-            Smp csmp;
-            csmp.on = smp.on;
-            csmp.key = smp.on ? child_key(smp.key, (uint32_t)k) : 0u;
-            const f3 cp = mk3(s0[k].x, s0[k].y, s0[k].z), cN = mk3(s1[k].x, s1[k].y, s1[k].z);
-            f3 cuvw = mk3(0, 0, 0);
-            if (TEXD) {
-                const float4 t = lv.fsuv[(size_t)f * 3 + k];
-                cuvw = mk3(t.x, t.y, t.z);
-                nx.fuv[idx] = t;
-            }
-            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp, GID && (info & RTU_FI_AMB));
-            nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
-            nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(BATD ? entry : csmp.key));
-            nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, GID ? fc.w : s0[k].w);  // recipe P: the chain id travels down
-            if (GID && (info & RTU_FI_AMB)) nx.famb[idx] = make_float4(ambI.x, ambI.y, ambI.z, 0.0f);
-            st[k] = (int)idx;
-            wantMain[k] = (cinfo & RTU_FI_MAIN) != 0;
-            wantRefl[k] = (cinfo & RTU_FI_C) != 0;
-        } else {
-            a.fcnt->overflow = 1;  // out of frame capacity: the host re-renders with more
-            st[k] = RTU_CH_MISS;
-        }
-    }
-    const bool pending = active && (st[0] >= 0 || st[1] >= 0 || st[2] >= 0);
-    st_out[0] = st[0]; st_out[1] = st[1]; st_out[2] = st[2];
-    {  // the new frames join the slot lists of their level — the lists of the frames that fire a refracted / mirror ray, so that k_trace visits the secondary slots only where there is a ray —; this frame the pending list of its own
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const unsigned long long a0 = __ballot(wantMain[0]), a1 = __ballot(wantMain[1]), a2 = __ballot(wantMain[2]);
-        const unsigned long long c0 = __ballot(wantRefl[0]), c1 = __ballot(wantRefl[1]), c2 = __ballot(wantRefl[2]);
-        const unsigned long long pm = __ballot(pending);
-        const uint32_t na = (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2)), nc = (uint32_t)(__popcll(c0) + __popcll(c1) + __popcll(c2));
-        uint32_t ba = 0, bc = 0, bp = 0;
-        if (lane == 0) {  // independent atomics: issued back to back, one wait
-            if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][cshard], na);
-            if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][cshard], nc);
-            if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][shard], (uint32_t)__popcll(pm));
-        }
-        ba = (uint32_t)__shfl((int)ba, 0);
-        bc = (uint32_t)__shfl((int)bc, 0);
-        bp = (uint32_t)__shfl((int)bp, 0);
-        const unsigned long long am[3] = {a0, a1, a2}, cm[3] = {c0, c1, c2};
-        uint32_t oa = ba, oc = bc;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (wantMain[k]) nx.lmain[(size_t)cshard * nx.cap_s + oa + (uint32_t)__popcll(am[k] & below)] = cfl[k];
-            if (wantRefl[k]) nx.lrefl[(size_t)cshard * nx.cap_s + oc + (uint32_t)__popcll(cm[k] & below)] = cfl[k];
-            oa += (uint32_t)__popcll(am[k]);
-            oc += (uint32_t)__popcll(cm[k]);
-        }
-        if (pending) lv.fpend[(size_t)shard * lv.cap_s + bp + (uint32_t)__popcll(pm & below)] = fl;
-    }
-    if (!active) return;
-    if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
-    if (!pending) {
-        const f3 one = mk3(1, 1, 1);
-        const f3 r = finalize<TEX>(s, m, info, direct, dir, p, N, st[0], st[1], st[2], one, one, one, bz, bfront, uvw, smp);
-        if (L == 0) {
-            if (GID) a.gi_res[((info & RTU_FI_AMB) ? 0u : a.gi_total) + (size_t)__float_as_uint(fc.w)] = make_float4(r.x, r.y, r.z, 0.0f);
-            else a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-        } else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
-    } else {
-        lv.fres[f] = make_float4(direct.x, direct.y, direct.z, 0.0f);  // the direct term waits for the children
-    }
-}
-
-template <bool STATS, int TEX>
-__global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
-    const LevelBuffers& lv = a.lv[L];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
-    const uint32_t chunks = kmax * RTU_SHARDS;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        const uint32_t fl = k * 64u + lane;
-        const bool active = fl < shard_count(a, L, shard);
-        int st[3];
-        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st);
-    }
-}
-
-// Frames that waited for children: combine bottom-up.
-// One frame that waited for its children (the body of k_combine; also used by k_tail).
-template <int TEX>
-__device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32_t f) {
-    const DevScene& s = a.scene;
-    const LevelBuffers& lv = a.lv[L];
-    const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
-    const float4 fa = lv.fa[f];
-    const uint32_t info = __float_as_uint(fa.w);
-    const int4 ch = lv.fchild[f];
-    const float4 fb = lv.fb[f], fc = lv.fc[f], fr = lv.fres[f];
-    const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
-    const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
-    const int st[3] = {ch.x, ch.y, ch.z};
-    f3 ret[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        ret[k] = mk3(1, 1, 1);
-        if (st[k] >= 0) {
-            const float4 r = nx.fres[st[k]];
-            ret[k] = mk3(r.x, r.y, r.z);
-        }
-    }
-    float bz = 0.0f;
-    bool bfront = true;
-    if ((info & RTU_FI_MAIN) && !(info & RTU_FI_TIR)) {
-        const float4* slotp = lv.fslot + ((size_t)f * 3 + SLOT_MAIN) * 2;
-        bz = slotp[0].w;
-        bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
-    }
-    f3 uvw = mk3(0, 0, 0);
-    if (TEXD) {
-        const float4 t = lv.fuv[f];
-        uvw = mk3(t.x, t.y, t.z);
-    }
-    const f3 r = finalize<TEX>(s, m, info, mk3(fr.x, fr.y, fr.z), dir, p, N, st[0], st[1], st[2], ret[0], ret[1], ret[2], bz, bfront, uvw,
-                               frame_smp<TEX>(a, L, fb.w));
-    if (L == 0) {
-        if (GID) a.gi_res[((info & RTU_FI_AMB) ? 0u : a.gi_total) + (size_t)__float_as_uint(fc.w)] = make_float4(r.x, r.y, r.z, 0.0f);
-        else a.out[__float_as_uint(fb.w)] = make_float4(r.x, r.y, r.z, fc.w);
-    } else lv.fres[f] = make_float4(r.x, r.y, r.z, 0.0f);
-}
-
-template <int TEX>
-__global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
-    const Stamp stamp(a, RTU_TL_COMBINE0 + L);
-    const LevelBuffers& lv = a.lv[L];
-    // only the frames k_consume listed as waiting for children
-    uint32_t pmax = a.fcnt->n_pending[L][lane_id() % RTU_SHARDS];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)pmax, off);
-        pmax = o > pmax ? o : pmax;
-    }
-    const uint32_t chunks = ((pmax + 63u) / 64u) * RTU_SHARDS;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        const uint32_t e = k * 64u + threadIdx.x;
-        if (e >= a.fcnt->n_pending[L][shard]) continue;
-        const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
-        combine_frame<TEX>(a, L, f);
-    }
-}
-
 // Self-test of the exact-division identity used by the slab and barycentric tests
 // (rtu_intersect.h, fdiv): pseudo-random bit patterns (all exponents, subnormals, zeros,
 // infinities, NaNs) plus same-exponent pairs; counts quotients whose bits differ from `/`.
 // ------------------------------------------------------------------------------------
-// THE TAIL. Deep recursion levels are often almost empty (two frames per level from level 3 on in
-// the headline scene) yet each costs four dependent launches (~4 us apiece, whatever their size)
-// plus a k_combine. When the previous frame showed that level Ls and below are small, the host
-// launches none of their kernels but this one: ONE WAVEFRONT PER FRAME of level Ls evaluates that
-// frame's whole Shade() subtree (levels Ls..max) — the same phases, the same device functions on
-// the same global frame arrays, sequenced inside the wavefront: rays eight at a time (one 8-lane
-// group each, cooperative BVH walk), consume with one lane per frame, children collected in LDS,
-// then the combines bottom-up. Correct for any number of frames (the count is only a hint for
-// the host's choice); the regular k_combine of levels < Ls follow.
-#define RTU_TAIL_CAP 256  // frames of one level in one subtree: at most 3^4 = 81 for a cut at level 1, 243 in theory
-template <int TEX>
-__global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * Ls);
-    __shared__ uint32_t s_stack[8 * RTU_STACK8];
-    __shared__ uint32_t s_cur[RTU_MAX_LEVELS][RTU_TAIL_CAP];  // my frames of each level
-    __shared__ uint32_t s_n[RTU_MAX_LEVELS];
-    __shared__ uint8_t s_pend[RTU_MAX_LEVELS][RTU_TAIL_CAP];  // the frame waits for children (fchild is only written for frames with secondary rays)
-    const uint32_t lane = threadIdx.x, grp = lane >> 3;
-    const bool leader = (lane & 7u) == 0;
-    const int levels = a.frame.max_bounce + 1;
-    const uint32_t nslots = a.nsl + 3u;
-    const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
-    const uint32_t roots = level_max_count(a, Ls) * RTU_SHARDS;  // (index within shard, shard) slots
-    Counters cnt = {};
-    for (uint32_t c = blockIdx.x; c < roots; c += gridDim.x) {
-        const uint32_t shard = c % RTU_SHARDS, rfl = c / RTU_SHARDS;
-        if (rfl >= shard_count(a, Ls, shard)) continue;  // wave-uniform
-        uint32_t n = 1;
-        if (lane == 0) {
-            s_cur[Ls][0] = shard * a.lv[Ls].cap_s + rfl;
-            s_n[Ls] = 1;
-        }
-        int last = Ls;
-        for (int L = Ls; L < levels && n > 0; L++) {
-            last = L;
-            __threadfence();  // s_cur and the frame records of this level are written
-            // ---- the rays of my frames: eight at a time, one 8-lane group each
-            const uint32_t total = n * nslots;
-            for (uint32_t base = 0; base < total; base += 8u) {
-                const uint32_t item = base + grp;
-                if (item < total) {
-                    const uint32_t i = item / nslots, slot = item - i * nslots;
-                    frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, slot, s_cur[L][i], s_stack + grp, cnt, leader, 8u, nullptr);
-                }
-            }
-            __threadfence();  // shadow results and secondary hits are visible to the consuming lanes
-            // ---- consume: one lane per frame, 64 at a time; the children become my frames of the next level
-            uint32_t nn = 0;
-            for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
-                const uint32_t i = b0 + lane;
-                const bool active = i < n;
-                const uint32_t f = active ? s_cur[L][i] : 0u;
-                int st[3];
-                consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st);
-                if (active) s_pend[L][i] = (st[0] >= 0 || st[1] >= 0 || st[2] >= 0) ? 1 : 0;
-                if (L + 1 < levels) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const bool has = active && st[k] >= 0;
-                        const unsigned long long m = __ballot(has);
-                        const uint32_t at = nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (has) {
-                            if (at < (uint32_t)RTU_TAIL_CAP) s_cur[L + 1][at] = (uint32_t)st[k];
-                            else a.fcnt->overflow = 1;  // cannot happen below 3^5 frames; reported like any overflow
-                        }
-                        nn += (uint32_t)__popcll(m);
-                    }
-                }
-            }
-            if (nn > (uint32_t)RTU_TAIL_CAP) nn = RTU_TAIL_CAP;
-            if (lane == 0 && L + 1 < levels) s_n[L + 1] = nn;
-            n = nn;
-        }
-        // ---- combine bottom-up what waited for children (levels Ls .. last-1)
-        for (int L = last - 1; L >= Ls; L--) {
-            __threadfence();
-            const uint32_t nL = s_n[L];
-            for (uint32_t i = lane; i < nL; i += 64u)
-                if (s_pend[L][i]) combine_frame<TEX>(a, L, s_cur[L][i]);
-        }
-        __threadfence();
-    }
-}
-
 __global__ void k_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* mismatches) {
     unsigned long long bad = 0;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n_pairs;
@@ -1138,72 +82,8 @@ __global__ void k_selftest_prims(unsigned long long n_rays, unsigned long long s
     if (bad) atomicAdd(mismatches, bad);
 }
 
-// ---- recipe P: MonteCarlo() of RenderFunctions.cpp:549-590 unrolled over the chain ---------------------
-// Depth k of a chain is shaded after depth k + 1: the AmbientLight MonteCarlo(h_k, 4 - k) appends has the
-// intensity c = Shade(h_k+1, its own AmbientLight) + Shade(h_k+1, lights) (:568-570), the environment along
-// the gather ray if it missed (:575), or 0.1 at the last bounce (:584). This kernel computes c for every
-// chain that has a hit of depth a.gi_depth and appends the two Shade() trees of that hit as level-0 frames.
-template <int TEX>
-__global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
-    const DevScene& s = a.scene;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t k = a.gi_depth;
-    const uint32_t chunks = (a.gi_total + 63u) / 64u;
-    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-        const uint32_t chain = c * 64u + lane;
-        const uint32_t shard = c % RTU_SHARDS;
-        const size_t hb = (size_t)k * 4u * a.gi_total + chain;
-        float4 hA = make_float4(0, 0, 0, 0), hB = hA, hC = hA, hD = hA;
-        bool want = false;
-        if (chain < a.gi_total) {
-            hB = a.gi_h[hb + a.gi_total];
-            want = (__float_as_uint(hB.w) & 1u) != 0;
-        }
-        if (want) {
-            hA = a.gi_h[hb];
-            hC = a.gi_h[hb + 2u * (size_t)a.gi_total];
-            if (TEXD) hD = a.gi_h[hb + 3u * (size_t)a.gi_total];
-        }
-        const uint32_t pk = __float_as_uint(hB.w);
-        const int mid = (int)(pk >> 2) - 1;
-        f3 amb = mk3(0.1f, 0.1f, 0.1f);  // :584
-        if (want && k < (uint32_t)RTU_GI_BOUNCES) {
-            const size_t hn = (size_t)(k + 1u) * 4u * a.gi_total + chain;
-            const uint32_t npk = __float_as_uint(a.gi_h[hn + a.gi_total].w);
-            if (npk & 1u) {
-                if ((int)(npk >> 2) - 1 < 0) {
-                    amb = (mk3(0, 0, 0) + mk3(1, 1, 1)) + mk3(1, 1, 1);  // a node without material shades white, twice
-                } else {
-                    const float4 ra = a.gi_res[chain], rd = a.gi_res[(size_t)a.gi_total + chain];
-                    amb = (mk3(0, 0, 0) + mk3(ra.x, ra.y, ra.z)) + mk3(rd.x, rd.y, rd.z);  // :569-570
-                }
-            } else {
-                const float4 nd = a.gi_h[hn + 2u * (size_t)a.gi_total];
-                amb = mk3(0, 0, 0) + ((TEXD && s.env.has_map) ? env_sample(s, mk3(nd.x, nd.y, nd.z)) : ld3(s.environment));  // :575
-            }
-        }
-        if (want && mid < 0) {  // no material at this hit: both trees are white, nothing to trace
-            a.gi_res[chain] = make_float4(1, 1, 1, 0);
-            a.gi_res[(size_t)a.gi_total + chain] = make_float4(1, 1, 1, 0);
-            want = false;
-        }
-        const f3 p = mk3(hA.x, hA.y, hA.z), N = mk3(hB.x, hB.y, hB.z), dir = mk3(hC.x, hC.y, hC.z), uvw = mk3(hD.x, hD.y, hD.z);
-        const bool front = (pk & 2u) != 0;
-        Smp sd, sa;
-        sd.on = sa.on = true;
-        sd.key = __float_as_uint(hC.w);                        // the tree lit by the scene's lights (:570, :135)
-        sa.key = child_key(sd.key, RTU_SLOT_AMBIENT_TREE);     // the tree lit by the AmbientLight (:569, :134)
-        uint32_t ia = 0, id = 0;
-        if (want) {
-            ia = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
-            id = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
-        }
-        const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw);
-        if (want && fa_idx != ~0u) a.lv[0].famb[fa_idx] = make_float4(amb.x, amb.y, amb.z, 0.0f);
-        append_root<TEX>(a, want, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw);
-    }
-}
 
+// ---- recipe P ----
 // the pixel of a chain: Shade(h_0, AmbientLight) + Shade(h_0, lights) (:134-135), z of the primary hit
 __global__ void __launch_bounds__(256) k_gi_final(KernelArgs a) {
     const uint32_t chain = blockIdx.x * 256u + threadIdx.x;
@@ -1212,52 +92,6 @@ __global__ void __launch_bounds__(256) k_gi_final(KernelArgs a) {
     if (!(pk & 1u)) return;  // missed (background) or a node without material (white): written by the chain's first launch
     const float4 ra = a.gi_res[chain], rd = a.gi_res[(size_t)a.gi_total + chain];
     a.out[chain] = make_float4(ra.x + rd.x, ra.y + rd.y, ra.z + rd.z, a.gi_h[chain].w);
-}
-
-template <int STACK, int TEX>
-int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL) {
-    const int levels = a.frame.max_bounce + 1;
-    const dim3 block(64);
-    // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
-    // workgroups, so the deeper, usually sparse levels get smaller grids
-    // (measured with 16 frames in flight: 32768 instead of 8192 workgroups for the one-lane-per-ray stage 2 and 4096
-    // instead of 2048 for k_consume balance the chunks better, -8 %; a single frame is unchanged)
-    const dim3 gridT(8192), gridN(32768), gridS(8192), gridF(4096), gridC(1024), gridCoop(512);
-    if (n_tiles == 0) return (int)hipSuccess;
-    const dim3 gridP((n_tiles + 3) / 4);
-    if (mode == RTU_LAUNCH_SHADE) {
-        hipLaunchKernelGGL((k_gi_roots<TEX>), gridN, block, 0, stream, a);
-    } else if (stats) {
-        hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
-    } else {
-        hipLaunchKernelGGL((k_primary<STACK, false, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
-        if (a.n_meshes) {  // without meshes nothing is ever deferred
-            hipLaunchKernelGGL((k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
-            hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
-        }
-    }
-    if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
-    // levels >= tail_from are evaluated by k_tail (fast variant only; the host passes tail_from >= 1, or 6 for none)
-    const int regular = (!stats && a.tail_from >= 1 && a.tail_from < levels) ? a.tail_from : levels;
-    for (int L = 0; L < regular; L++) {
-        const int ph = 1 + L;  // defer list of this level's tracing phase
-        if (stats) {
-            hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
-            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
-            hipLaunchKernelGGL((k_consume<true, TEX>), gridF, block, 0, stream, a, L);
-        } else {
-            const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
-            hipLaunchKernelGGL((k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
-            if (a.n_meshes) {
-                hipLaunchKernelGGL((k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
-                hipLaunchKernelGGL((k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
-            }
-            hipLaunchKernelGGL((k_consume<false, TEX>), gridF, block, 0, stream, a, L);
-        }
-    }
-    if (regular < levels) hipLaunchKernelGGL((k_tail<TEX>), dim3(8192), block, 0, stream, a, regular);
-    for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
-    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -1333,28 +167,30 @@ int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed
     return (int)hipGetLastError();
 }
 
-template <int FEAT>
-static int launch_feat(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream) {
-    if (bvh_stack_needed <= 16) return launch_all<16, FEAT>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 24) return launch_all<24, FEAT>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 32) return launch_all<32, FEAT>(args, n_tiles, stats, stream);
-    return launch_all<RTU_MAX_BVH_STACK, FEAT>(args, n_tiles, stats, stream);
-}
+
+int rtu_launch_feat0(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat1(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat2(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat3(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat4(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat5(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat10(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat11(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
 
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode) {
     // textured scenes, sampled frames and batches of frames run their own instantiations: the others carry no
-    // uvw, sample nothing and draw nothing. Recipe P has one stack size (the largest).
+    // uvw, sample nothing and draw nothing.
     if (mode != RTU_LAUNCH_ALL) {
-        if (args.scene.textured) return launch_all<RTU_MAX_BVH_STACK, 11>(args, n_tiles, stats, stream, mode);
-        return launch_all<RTU_MAX_BVH_STACK, 10>(args, n_tiles, stats, stream, mode);
+        if (args.scene.textured) return rtu_launch_feat11(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        return rtu_launch_feat10(args, n_tiles, bvh_stack_needed, stats, stream, mode);
     }
     switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0))) {
-        case 0: return launch_feat<0>(args, n_tiles, bvh_stack_needed, stats, stream);
-        case 1: return launch_feat<1>(args, n_tiles, bvh_stack_needed, stats, stream);
-        case 2: return launch_feat<2>(args, n_tiles, bvh_stack_needed, stats, stream);
-        case 3: return launch_feat<3>(args, n_tiles, bvh_stack_needed, stats, stream);
-        case 4: return launch_feat<4>(args, n_tiles, bvh_stack_needed, stats, stream);
-        default: return launch_feat<5>(args, n_tiles, bvh_stack_needed, stats, stream);
+        case 0: return rtu_launch_feat0(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        case 1: return rtu_launch_feat1(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        case 2: return rtu_launch_feat2(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        case 3: return rtu_launch_feat3(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        case 4: return rtu_launch_feat4(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        default: return rtu_launch_feat5(args, n_tiles, bvh_stack_needed, stats, stream, mode);
     }
 }
 

@@ -31,6 +31,10 @@ struct Hit {  // HitInfo (scene.h:150-163); uvw is maintained for textured scene
     bool  front;
 };
 
+__device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Init, scene.h:162
+    h.z = tmax; h.front = true; h.node = -1; h.p = mk3(0, 0, 0); h.N = mk3(0, 0, 0);
+}
+
 struct Counters {
     unsigned prim, prim_hit, sec, shd, node, mesh, inner, leafv, leafe, tri, acc;
 };

@@ -115,6 +115,12 @@ const char* rtu_last_error(const RtuContext* ctx);
  * to replace the scene. */
 int  rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* scene);
 
+/* The validation rtu_upload_scene runs first, on its own: every index the kernels follow (node parents, mesh,
+ * material and texture ids, vertex / normal / texture-vertex indices, BVH children, leaf ranges, element ids) is
+ * range-checked so that a malformed scene is an error code, never an out-of-bounds access on the GPU. Pure host
+ * code, needs no GPU and no context; the message goes to err_buf (may be NULL). */
+int  rtu_validate_scene(const RtuSceneDesc* scene, char* err_buf, size_t err_len);
+
 /* Fill width/height, cam_pos/origin/u/v from the camera (fp64 tan chain of
  * RenderFunctions.cpp:247 evaluated on the host, once per frame), single shard,
  * max_bounce 5, no stats. Pure host arithmetic; needs no GPU. */
@@ -156,7 +162,10 @@ int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz,
  * arrays (one frame per pixel per level to begin with); RTU_ERR_CAPACITY means a level
  * overflowed: the arrays are re-provisioned from the counts the frame reported — render the
  * frame again (at most one round per recursion level). rtu_render_frame does the check and
- * the re-render itself. */
+ * the re-render itself. The report is STICKY: it covers every launch sequence queued on this context since the
+ * previous rtu_frame_status (or synchronous render), not only the last one — a caller that pipelines several
+ * rtu_render_frame(s)_device calls with different cameras and checks once learns that SOME frame of them is
+ * incomplete and renders them again. */
 int  rtu_frame_status(RtuContext* ctx);
 
 /* Diagnostic: render one frame with every wavefront stamping the GPU's constant clock on entry

@@ -238,6 +238,9 @@ static void Flatten(Flat& F, RtuSceneDesc& d) {
         RtuMaterial m;
         memset(&m, 0, sizeof m);
         const MtlBlinn* b = dynamic_cast<const MtlBlinn*>(materials[i]);
+        // MultiMtl::Shade forwards to mtls[hInfo.mtlID] and mtlID is never written (scene.h:159,162): sub-material 0
+        if (const MultiMtl* mm = dynamic_cast<const MultiMtl*>(materials[i]))
+            b = mm->mtls.empty() ? NULL : dynamic_cast<const MtlBlinn*>(mm->mtls[0]);
         if (!b) { fprintf(stderr, "non-Blinn material: outside the flattened format\n"); exit(2); }
         auto put = [](float* dst, const Color& c) { dst[0] = c.r; dst[1] = c.g; dst[2] = c.b; };
         put(m.diffuse, b->diffuse.GetColor());

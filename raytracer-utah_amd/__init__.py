@@ -56,6 +56,14 @@ class RtuTexMap(ctypes.Structure):
                 ("pos", ctypes.c_float * 3), ("reserved", ctypes.c_int32)]
 
 
+class RtuMesh(ctypes.Structure):
+    _fields_ = [("nv", ctypes.c_uint32), ("nf", ctypes.c_uint32), ("nvn", ctypes.c_uint32), ("nvt", ctypes.c_uint32),
+                ("n_bvh_nodes", ctypes.c_uint32), ("n_elements", ctypes.c_uint32), ("bvh_depth", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("bound_min", ctypes.c_float * 3), ("bound_max", ctypes.c_float * 3),
+                ("v", ctypes.c_void_p), ("f", ctypes.c_void_p), ("vn", ctypes.c_void_p), ("fn", ctypes.c_void_p),
+                ("vt", ctypes.c_void_p), ("ft", ctypes.c_void_p), ("bvh", ctypes.c_void_p), ("elements", ctypes.c_void_p)]
+
+
 class RtuSceneDesc(ctypes.Structure):
     _fields_ = [("n_nodes", ctypes.c_uint32), ("n_materials", ctypes.c_uint32), ("n_lights", ctypes.c_uint32),
                 ("n_meshes", ctypes.c_uint32), ("nodes", ctypes.c_void_p), ("materials", ctypes.c_void_p),
@@ -120,7 +128,7 @@ def _sig(lib, name, restype, *argtypes):
 
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
-               "rtu_upload_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
+               "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
                "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
@@ -129,6 +137,7 @@ _sig(hip, "rtu_create_context", _P, _I, ctypes.POINTER(_I))
 _sig(hip, "rtu_destroy_context", None, _P)
 _sig(hip, "rtu_last_error", ctypes.c_char_p, _P)
 _sig(hip, "rtu_upload_scene", _I, _P, _P)
+_sig(hip, "rtu_validate_scene", _I, _P, ctypes.c_char_p, ctypes.c_size_t)
 _sig(hip, "rtu_frame_setup", _I, ctypes.POINTER(RtuCamera), _I, _I, ctypes.POINTER(RtuFrameDesc))
 _sig(hip, "rtu_shard_rows", _I, ctypes.POINTER(RtuFrameDesc))
 _sig(hip, "rtu_shard_max_rows", _I, _I, _I)

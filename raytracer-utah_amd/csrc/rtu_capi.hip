@@ -461,6 +461,12 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
             if (m.f[i] >= m.nv) return fail(ctx, RTU_ERR_ARG, "mesh %u: vertex index out of range", mi);
             if (m.fn[i] >= m.nvn) return fail(ctx, RTU_ERR_ARG, "mesh %u: normal index out of range", mi);
         }
+        // texture coordinates are optional, but half a set or an index past nvt would be read on every accepted hit
+        if ((m.vt != nullptr) != (m.ft != nullptr) || ((m.vt || m.ft) && m.nvt == 0) || (m.nvt != 0 && !m.vt))
+            return fail(ctx, RTU_ERR_ARG, "mesh %u: texture vertices and texture faces must come together (nvt %u)", mi, m.nvt);
+        if (m.ft)
+            for (uint32_t i = 0; i < m.nf * 3; i++)
+                if (m.ft[i] >= m.nvt) return fail(ctx, RTU_ERR_ARG, "mesh %u: texture-vertex index out of range", mi);
         for (uint32_t i = 0; i < m.n_elements; i++)
             if (m.elements[i] >= m.nf) return fail(ctx, RTU_ERR_ARG, "mesh %u: element out of range", mi);
         // every node reachable from the root must be well formed; children have larger
@@ -623,7 +629,9 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     }
     bool stats = frame->collect_stats != 0;
     if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
-    RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, sizeof(FrameCounters), stream));
+    // the append counters start at zero; `overflow` is STICKY — launches only ever set it, check_overflow reads and clears
+    // it — so that a frame that ran out of capacity is reported even when later launch sequences were queued behind it
+    RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, offsetof(FrameCounters, overflow), stream));
     KernelArgs a;
     memset(&a, 0, sizeof a);
     a.scene = ctx->dscene;
@@ -717,6 +725,7 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
         learn_tail(ctx, h);
         return RTU_OK;
     }
+    RTU_HIP(ctx, hipMemset(&ctx->fcnt->overflow, 0, sizeof(uint32_t)));  // reported: the next status starts clean
     bool grew = false;
     for (int L = 1; L < RTU_MAX_LEVELS; L++) {
         uint32_t need = 0;
@@ -736,7 +745,7 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
         ctx->want_defer_s = dneed + dneed / 4;
         grew = true;
     }
-    if (!grew) {  // should not happen: the flag is only set next to a counter that ran over
+    if (!grew) {  // the overflow was an EARLIER launch sequence's (the counts are the last one's): grow every level
         for (int L = 1; L < RTU_MAX_LEVELS; L++) ctx->want_cap_s[L] = ctx->lv[L].cap_s * 2;
     }
     return RTU_OK;
@@ -882,6 +891,15 @@ void rtu_destroy_context(RtuContext* ctx) {
 }
 
 const char* rtu_last_error(const RtuContext* ctx) { return ctx ? ctx->error.c_str() : "context is NULL"; }
+
+int rtu_validate_scene(const RtuSceneDesc* s, char* err_buf, size_t err_len) {
+    RtuContext tmp;  // plain host state: nothing here touches a GPU
+    const int rc = validate(&tmp, s);
+    if (err_buf && err_len) {
+        snprintf(err_buf, err_len, "%s", tmp.error.c_str());
+    }
+    return rc;
+}
 
 int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     if (!ctx) return RTU_ERR_ARG;

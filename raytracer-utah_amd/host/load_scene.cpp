@@ -300,10 +300,12 @@ struct Loader {
                 if (!obj) {
                     std::unique_ptr<TriObj> t(new TriObj);
                     if (!t->Load(remap(key).c_str(), mtlName == nullptr)) {
-                        // the reference prints the error and leaves the node without an object (:205-207)
-                        if (sg.error.empty() && t->error.find("not supported") != std::string::npos) sg.error = t->error;
+                        // the reference prints the error and leaves the node without an object (:205-207); a face that
+                        // points outside its vertex lists (where the reference reads out of bounds) fails the scene
+                        if (sg.error.empty() && t->error.find("does not exist") != std::string::npos) sg.error = t->error;
                     } else {
                         obj = t.get();
+                        if (t->NM() > 0) MakeMultiMtl(*t, node, key);
                         sg.objList.emplace_back(key, std::move(t));
                     }
                 }
@@ -313,6 +315,50 @@ struct Loader {
         for (auto& c : e.children)
             if (same(c->name, "object")) LoadNode(node, *c);
         LoadTransform(*node, e);  // after the children, :253-258
+    }
+
+    // File texture by name, shared through textureList (Texture* ReadTexture(const char*), xmlload.cpp:535-555)
+    const Texture* ReadTextureFile(const char* texName) {
+        for (auto& t : sg.textureList)
+            if (t->name == texName) return t.get();
+        std::unique_ptr<Texture> f(new Texture);
+        f->type = RTU_TEX_FILE;
+        f->name = texName;
+        if (!LoadTextureFile(remap(texName).c_str(), *f)) return nullptr;  // stays TextureMap(NULL): black
+        sg.textureList.push_back(std::move(f));
+        return sg.textureList.back().get();
+    }
+
+    // The .obj of a node without material= brought its own materials (usemtl / .mtl): one MtlBlinn per material,
+    // together a MultiMtl named like the file, bound to the node by that name (xmlload.cpp:208-241) — unless a
+    // material of that name already exists. Reproduced as written, including :222 (map_Ks lands on the DIFFUSE
+    // texture, replacing map_Kd's) and the unused gloss of :226.
+    void MakeMultiMtl(const TriObj& obj, Node* node, const std::string& name) {
+        for (auto& m : sg.materials)
+            if (m->name == name) return;
+        std::unique_ptr<MultiMtl> mm(new MultiMtl);
+        auto set_map = [&](TexturedColor& tc, const std::string& file) {
+            tc.map.reset(new TextureMap);
+            tc.map->texture = ReadTextureFile(file.c_str());
+        };
+        for (const ObjMtl& mtl : obj.mtls) {
+            MtlBlinn* m = new MtlBlinn;
+            m->diffuse.SetColor(Color(mtl.Kd[0], mtl.Kd[1], mtl.Kd[2]));
+            m->specular.SetColor(Color(mtl.Ks[0], mtl.Ks[1], mtl.Ks[2]));
+            m->glossiness = mtl.Ns;
+            m->ior = mtl.Ni;
+            if (mtl.has_map_Kd) set_map(m->diffuse, mtl.map_Kd);
+            if (mtl.has_map_Ks) set_map(m->diffuse, mtl.map_Ks);
+            if (mtl.illum > 2 && mtl.illum <= 7) {
+                m->reflection.SetColor(Color(mtl.Ks[0], mtl.Ks[1], mtl.Ks[2]));
+                if (mtl.has_map_Ks) set_map(m->reflection, mtl.map_Ks);
+                if (mtl.illum >= 6) m->refraction.SetColor(Color(-(mtl.Tf[0] - 1), -(mtl.Tf[1] - 1), -(mtl.Tf[2] - 1)));  // 1 - Color is -(c - 1), cyColor.h:56
+            }
+            mm->AppendMaterial(m);
+        }
+        mm->name = name;
+        sg.materials.emplace_back(std::move(mm));
+        nodeMtlList.emplace_back(node, name);
     }
 
     // LoadMaterial (xmlload.cpp:294-370)
@@ -507,6 +553,8 @@ Scene* Flatten(const SceneGraph& sg, std::string& err) {
     bool any_map = false;
     for (auto& mp : sg.materials) {
         const MtlBlinn* b = dynamic_cast<const MtlBlinn*>(mp.get());
+        if (const MultiMtl* mm = dynamic_cast<const MultiMtl*>(mp.get()))
+            b = mm->mtls.empty() ? nullptr : mm->mtls[0].get();  // hInfo.mtlID is always 0 (scene.h:159,162; materials.h:66)
         RtuMaterial m;
         memset(&m, 0, sizeof m);
         if (!b) { err = "unsupported material class"; return nullptr; }

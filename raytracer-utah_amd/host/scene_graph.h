@@ -78,17 +78,34 @@ public:
 class Sphere : public Object { public: int Type() const override { return RTU_OBJ_SPHERE; } };
 class Plane : public Object { public: int Type() const override { return RTU_OBJ_PLANE; } };
 
+// cy::TriMesh::Mtl (cyTriMesh.h:72-103): a material of a .mtl library that the .obj uses (usemtl) — the fields
+// LoadNode turns into a MtlBlinn (xmlload.cpp:209-232)
+struct ObjMtl {
+    std::string used_name;   // as written after usemtl
+    std::string name;        // as written after newmtl (empty if no library defines it: the defaults below stay)
+    float Ka[3] = {0, 0, 0}, Kd[3] = {1, 1, 1}, Ks[3] = {0, 0, 0}, Tf[3] = {0, 0, 0};
+    float Ns = 0, Ni = 1;
+    int   illum = 2;
+    bool  has_map_Kd = false, has_map_Ks = false;
+    std::string map_Kd, map_Ks;
+    uint32_t first_face = 0, face_count = 0;   // while reading: the first face line under it, faces read under it
+    uint32_t cumulative_face_count = 0;        // mcfc: faces of materials 0..this one after regrouping
+};
+
 // objects.h:45-66 = cyTriMesh + cyBVHTriMesh
 class TriObj : public Object {
 public:
     int Type() const override { return RTU_OBJ_TRIMESH; }
     // objects.h:52-60: LoadFromFileObj, ComputeNormals if none, ComputeBoundingBox, bvh.SetMesh(this,4)
     bool Load(const char* filename, bool loadMtl);
+    unsigned NM() const { return (unsigned)mtls.size(); }
     MeshData data;
+    std::vector<ObjMtl> mtls;   // loadMtl only
     std::string error;
 };
 
-bool LoadObjFile(const char* filename, bool loadMtl, MeshData& out, std::string& err);  // cyTriMesh.h:263-547
+// cyTriMesh.h:263-547; mtls_out (may be NULL): the materials the file uses, filled from its .mtl libraries
+bool LoadObjFile(const char* filename, bool loadMtl, MeshData& out, std::string& err, std::vector<ObjMtl>* mtls_out = nullptr);
 void ComputeNormals(MeshData& m);                                                        // cyTriMesh.h:248-261
 void ComputeBoundingBox(MeshData& m);                                                    // cyTriMesh.h:226-246
 void BuildBVH(MeshData& m, unsigned maxElementsPerNode);                                 // cyBVH.h:122-142,242-328
@@ -134,6 +151,14 @@ public:
         diffuse.color = Color(0.5f, 0.5f, 0.5f);
         specular.color = Color(0.7f, 0.7f, 0.7f);
     }
+};
+
+// materials.h:61-82. HitInfo::mtlID is initialised to 0 and written by nobody (scene.h:159,162), so Shade() always
+// forwards to the FIRST sub-material: that is what Flatten() emits for a node bound to a MultiMtl.
+class MultiMtl : public Material {
+public:
+    std::vector<std::unique_ptr<MtlBlinn>> mtls;
+    void AppendMaterial(MtlBlinn* m) { mtls.emplace_back(m); }
 };
 
 // scene.h:280-293, lights.h

@@ -17,7 +17,21 @@ EXTRA_TAGS = ["p1test_200x150", "p2_200x150", "p3box_200x150", "p5_200x150", "p5
               "p13_200x150"]  # the reference's other deterministic scenes
 SMALL_TAGS = SMALL_TAGS + EXTRA_TAGS
 ALL_TAGS = SMALL_TAGS + FULL_TAGS
-TEX_TAGS = ["p7_200x150"]  # textured
+TEX_TAGS = ["p7_200x150", "mtl_160x120"]  # textured; mtl: an .obj with its own .mtl materials -> MultiMtl (row f3)
+LOCAL_SCENES = {"mtl_160x120": "multimtl/scene.xml"}  # scenes written for this repository (tests/scenes), not the reference's
+
+
+def instantiate_scene(rel, dst):
+    """Copy tests/scenes/<dir of rel> to dst with its @DIR@ placeholders (absolute paths of .obj / texture files,
+    as the reference's scene files carry them) pointing at dst; returns the path of the scene XML."""
+    src = os.path.join(REPO, "tests", "scenes", os.path.dirname(rel))
+    os.makedirs(str(dst), exist_ok=True)
+    for name in os.listdir(src):
+        data = open(os.path.join(src, name), "rb").read()
+        if name.endswith((".xml", ".mtl", ".obj")):
+            data = data.replace(b"@DIR@", str(dst).encode())
+        open(os.path.join(str(dst), name), "wb").write(data)
+    return os.path.join(str(dst), os.path.basename(rel))
 # stochastic effects (SURVEY row f1), recipe S: glossy + soft + textured; depth of field; glossy + soft; 12 soft lights + glossy refraction; teapot + soft
 SAMPLED_TAGS = ["p10_s4_160x120", "p9_s3_160x120", "p11gs_s2_160x90", "p11x86_s1_120x90", "teapot1_s2_160x90"]
 PATH_TAGS = ["p11_p2_120x68", "p13_p2_96x72"]  # recipe P (config 5): + the Monte-Carlo gather

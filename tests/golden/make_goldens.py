@@ -54,6 +54,9 @@ CONFIGS = [
     ("p11gs_s2_160x90", "Project11/scene_glossy_soft.xml", 160, 90, True, 2),
     ("p11x86_s1_120x90", "Project11/scene_86.xml", 120, 90, True, 1),
     ("teapot1_s2_160x90", "Teapot/scene.xml", 160, 90, True, 2),
+    # row f3: an .obj that brings its own materials (usemtl / .mtl -> MultiMtl, xmlload.cpp:199-243) — a scene written for
+    # this repository (tests/scenes/multimtl, "@" = repository path), run through the compiled reference like the others
+    ("mtl_160x120", "@tests/scenes/multimtl/scene.xml", 160, 120, True),
     # recipe P (config 5): recipe S plus the 4-bounce Monte-Carlo gather of Render(); 8th field "P"
     ("p11_p2_120x68", "Project11/scene.xml", 120, 68, True, 2, "P"),
     ("p13_p2_96x72", "Project13/scene.xml", 96, 72, True, 2, "P"),
@@ -72,7 +75,8 @@ def main():
         paths = len(cfg) > 6 and cfg[6] == "P"
         if only and tag not in only:
             continue
-        subprocess.check_call([RUN, scene, str(W), str(H), tag, "8"] + ([str(spp)] if spp else []) + (["paths"] if paths else []))
+        scene_arg = os.path.join(REPO, scene[1:]) if scene.startswith("@") else scene
+        subprocess.check_call([RUN, scene_arg, str(W), str(H), tag, "8"] + ([str(spp)] if spp else []) + (["paths"] if paths else []))
         src = os.path.join(REPO, "oracle", "_ref", "out", tag)
         dst = os.path.join(HERE, tag)
         os.makedirs(dst, exist_ok=True)

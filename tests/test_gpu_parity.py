@@ -429,9 +429,21 @@ def test_frame_capacity_overflow_is_detected_and_repaired(pkg, orc, tmp_path):
         nbytes = W * H * 16
         d = pkg.hip.rtu_device_alloc(ctx._h, nbytes)
         ctx.render_device(fr, d, None)
+        # the report is sticky: a later launch sequence that fits (the camera turned away from the ball: bare wall, no
+        # child frames) queued behind the overflowed one must not erase it
+        cam_away = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        for k in range(3):
+            cam_away.dir[k] = -cam_away.dir[k]
+        d2 = pkg.hip.rtu_device_alloc(ctx._h, nbytes)
+        ctx.render_device(pkg.frame_setup(cam_away, W, H), d2, None)
         with pytest.raises(pkg.RtuError) as e:
             ctx.frame_status()
         assert e.value.code == pkg.RTU_ERR_CAPACITY
+        ctx.frame_status()  # ... and is cleared by being read
+        away = np.empty((H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, away.ctypes.data, d2, nbytes) == 0
+        pkg.hip.rtu_device_free(ctx._h, d2)
+        assert (away[..., 3] > 40).all()  # only the room's wall in view
         for _ in range(8):  # every report grows the capacity of at least one more recursion level
             ctx.render_device(fr, d, None)
             try:

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ALL_TAGS, REFERENCE, REPO, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, read_png
+from conftest import ALL_TAGS, LOCAL_SCENES, REFERENCE, REPO, SAMPLED_TAGS, SMALL_TAGS, TEX_TAGS, instantiate_scene, read_png
 
 MAC_PREFIX = "/Users/Peter/GitRepos/RayTracer-Utah"
 SCENES = {
@@ -85,7 +85,7 @@ def test_blob_rejects_garbage(pkg, golden):
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="scene files only exist in the authoring container")
-@pytest.mark.parametrize("tag", ALL_TAGS + TEX_TAGS + SAMPLED_TAGS)
+@pytest.mark.parametrize("tag", [t for t in ALL_TAGS + TEX_TAGS + SAMPLED_TAGS if t not in LOCAL_SCENES])
 def test_loader_matches_reference_scene_values(pkg, golden, tag):
     """Own XML + OBJ reader + BVH build vs the blob dumped from the reference's in-memory
     scene graph after ITS LoadScene(): every float of every node/material/light/camera,
@@ -94,6 +94,37 @@ def test_loader_matches_reference_scene_values(pkg, golden, tag):
     s = pkg.Scene.from_xml(os.path.join(REFERENCE, "SceneFiles", SCENES[tag]), MAC_PREFIX, REFERENCE)
     s.set_resolution(g.width, g.height)
     assert s.to_blob_bytes() == g.scene(pkg).to_blob_bytes()
+
+
+@pytest.mark.parametrize("tag", sorted(LOCAL_SCENES))
+def test_loader_matches_reference_on_obj_with_its_own_materials(pkg, golden, tag, tmp_path):
+    """Row f3: a node without material= whose .obj names materials of a .mtl library (xmlload.cpp:199-243,
+    cyTriMesh.h:452-547): faces regrouped material by material, a MultiMtl of one MtlBlinn per material bound to
+    the node, map_Kd / map_Ks as the reference wires them — against the blob the COMPILED REFERENCE flattened
+    from the same files (tests/golden/make_goldens.py), byte for byte. Runs everywhere: the scene is this
+    repository's own (tests/scenes)."""
+    g = golden(tag)
+    s = pkg.Scene.from_xml(instantiate_scene(LOCAL_SCENES[tag], tmp_path / "scene"))
+    s.set_resolution(g.width, g.height)
+    assert s.to_blob_bytes() == g.scene(pkg).to_blob_bytes()
+    assert s.desc.n_textures == 1 and s.desc.n_meshes == 1
+
+
+def test_obj_faces_that_point_nowhere_are_an_error_not_a_crash(pkg, tmp_path):
+    """The reference indexes its vertex arrays with whatever a face line says (cyTriMesh.h:421-431); here a literal 0,
+    an index past the last vertex / texture vertex / normal, or a relative index before the first one fails the load
+    before normals, bounds or the BVH are computed from it."""
+    xml = """<xml><scene><object type="obj" name="{obj}" material="m"/><material type="blinn" name="m"/></scene>
+             <camera><position x="0" y="-5" z="0"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/></camera></xml>"""
+    good = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n"
+    for face in ("f 0 1 2", "f 1 2 4", "f -4 1 2", "f 1/2 2/1 3/1", "f 1//2 2//1 3//1", "f 1 2 3\nf 1 2 99999999999"):
+        (tmp_path / "bad.obj").write_text(good + face + "\n")
+        (tmp_path / "s.xml").write_text(xml.format(obj=tmp_path / "bad.obj"))
+        with pytest.raises(pkg.RtuError, match="does not exist"):
+            pkg.Scene.from_xml(str(tmp_path / "s.xml"))
+    (tmp_path / "bad.obj").write_text(good + "f 1/1/1 2/1/1 -1/-1/-1\n")
+    s = pkg.Scene.from_xml(str(tmp_path / "s.xml"))
+    assert s.desc.n_meshes == 1
 
 
 def test_loader_error_paths(pkg, tmp_path):
@@ -320,3 +351,33 @@ def test_texture_files_decode(pkg, tmp_path):
     sc = pkg.Scene.from_xml(str(xml))
     d = sc.desc
     assert d.n_textures == 0 and not d.material_maps
+
+
+def test_validate_rejects_bad_mesh_indices(pkg, golden):
+    """rtu_validate_scene (what rtu_upload_scene runs first; pure host code): an index the kernels would follow
+    out of its array is an error code on the CPU, never a fault on the GPU — texture-vertex indices included
+    (they are read on every accepted triangle hit of a textured scene)."""
+    import ctypes
+    scene = golden("p7_200x150").scene(pkg)
+    err = ctypes.create_string_buffer(256)
+    assert pkg.hip.rtu_validate_scene(scene.desc_ptr, err, 256) == 0
+    m = ctypes.cast(scene.desc.meshes, ctypes.POINTER(pkg.RtuMesh))[0]
+    assert m.nvt > 0 and m.ft and m.vt
+    u32 = ctypes.POINTER(ctypes.c_uint32)
+    for field, limit, what in (("ft", m.nvt, b"texture-vertex"), ("f", m.nv, b"vertex index"), ("fn", m.nvn, b"normal index")):
+        arr = ctypes.cast(getattr(m, field), u32)
+        keep = arr[5]
+        arr[5] = limit  # one past the last element
+        assert pkg.hip.rtu_validate_scene(scene.desc_ptr, err, 256) == pkg.RTU_ERR_ARG
+        assert what in err.value, err.value
+        arr[5] = keep
+    keep = m.vt
+    m.vt = None  # texture faces without texture vertices
+    assert pkg.hip.rtu_validate_scene(scene.desc_ptr, err, 256) == pkg.RTU_ERR_ARG
+    m.vt = keep
+    keep = m.nvt
+    m.nvt = 0
+    assert pkg.hip.rtu_validate_scene(scene.desc_ptr, err, 256) == pkg.RTU_ERR_ARG
+    m.nvt = keep
+    assert pkg.hip.rtu_validate_scene(scene.desc_ptr, err, 256) == 0
+    assert pkg.hip.rtu_validate_scene(None, err, 256) == pkg.RTU_ERR_ARG

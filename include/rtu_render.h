@@ -55,7 +55,9 @@ typedef struct RtuFrameDesc {
     int32_t width, height;
     int32_t shard_rank, shard_count;  /* 0,1 for a single GPU */
     int32_t max_bounce;               /* 5, RenderFunctions.cpp:134 */
-    int32_t collect_stats;            /* 1: fill the ray / traversal counters (slower kernel variant) */
+    int32_t collect_stats;            /* 1: fill the ray / traversal counters RtuStats (the counting variant: the reference's own
+                                         tree, no culling — slower); 2: the FAST variant as it is timed, counting per kernel what it
+                                         touches (RtuTouched; recipe W only) */
     int32_t coop_threshold;           /* tuning: a deferred-ray list shorter than this is traced by the
                                          cooperative (8 lanes per ray) kernels; 0 = default */
     int32_t samples;                  /* 0: recipe W, one ray through every pixel centre (scenes with stochastic
@@ -207,6 +209,32 @@ int  rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_
 
 /* Counters of the last frame rendered with collect_stats=1 (synchronises). */
 int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
+
+/* Touched-bytes mode (collect_stats == 2): what the kernels of the FAST variant — the ones bench.py times — read and write,
+ * per kernel launch of the most recent launch sequence. A slot is a kernel's place in the sequence (rtu_kernel_slot_name:
+ * "k_primary", "k_primary2c", "k_primary2", "k_trace(L0)", "k_trace2c(L0)", "k_trace2(L0)", "k_consume(L0)", ..., "k_combine(L0)", ...;
+ * the tail kernel reports in the k_trace slot of its cut level). The images of this mode are those of the fast variant, bit for bit.
+ * ALGORITHMIC bytes of a launch (rtu_touched_bytes; cache-agnostic, every access counted where it is made):
+ *   48 node_tests (itm + pos) + 24 mesh_box_tests (bounding box) + 84 xform_levels (tm + pos + itm of FromNodeCoords)
+ *   + 112 inner4 (7 float4 of a 4-wide node) + 256 inner8 (8 x 32 B child records) + 64 inner_ref (a sibling pair of the reference's
+ *   tree: exact-tie / stack-overflow fallback) + 64 tri_tests (triangle record) + 100 winners (element, face and normal indices, three
+ *   vertices, three normals; 148 with texture vertices) + record_bytes (frame records, lists, shadow results, pixels: counted at
+ *   every load / store). SURVEY 8d's per-unit figures with the record sizes of THIS layout in place of the reference's. */
+#define RTU_KERNEL_SLOTS 40
+typedef struct RtuTouched {
+    uint64_t rays;            /* Trace / ShadowTrace walks started by this launch */
+    uint64_t node_tests, mesh_box_tests, inner4, inner8, inner_ref, tri_tests, winners, xform_levels;
+    uint64_t record_bytes;
+} RtuTouched;
+int         rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots);   /* synchronises; returns the slots written */
+unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured);
+const char* rtu_kernel_slot_name(int slot);
+
+/* Measurement helper for bench.py: bracket every launch of the kernel in `slot` with HIP events on the launch stream, from now on
+ * (slot < 0: stop). rtu_probe_read synchronises, returns the summed duration and the number of launches measured since the last
+ * read (at most 64 are kept) and starts over. Recipe W launch sequences only. */
+int  rtu_probe_kernel(RtuContext* ctx, int slot);
+int  rtu_probe_read(RtuContext* ctx, float* total_ms_out, int* launches_out);
 
 /* Measurement helper for bench.py: launch the render kernel `iters` times
  * back-to-back on `hip_stream`, bracketed by HIP events recorded on that same

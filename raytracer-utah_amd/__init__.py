@@ -92,6 +92,18 @@ class RtuStats(ctypes.Structure):
         return {n: int(getattr(self, n)) for n in STAT_FIELDS}
 
 
+TOUCH_FIELDS = ["rays", "node_tests", "mesh_box_tests", "inner4", "inner8", "inner_ref", "tri_tests", "winners", "xform_levels", "record_bytes"]
+KERNEL_SLOTS = 40
+
+
+class RtuTouched(ctypes.Structure):
+    """rtu_render.h: what one kernel launch of the fast variant touched (collect_stats == 2)."""
+    _fields_ = [(n, ctypes.c_uint64) for n in TOUCH_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in TOUCH_FIELDS}
+
+
 def algorithmic_bytes(stats, pixels):
     """cache-agnostic bytes the path touches for one frame."""
     s = stats if isinstance(stats, dict) else stats.as_dict()
@@ -129,7 +141,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -147,6 +159,11 @@ _sig(hip, "rtu_render_frames_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _I, 
 _sig(hip, "rtu_pack_image_device", _I, _P, _P, ctypes.c_size_t, _P, _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
+_sig(hip, "rtu_get_touched", _I, _P, ctypes.POINTER(RtuTouched), _I)
+_sig(hip, "rtu_touched_bytes", ctypes.c_uint64, ctypes.POINTER(RtuTouched), _I)
+_sig(hip, "rtu_kernel_slot_name", ctypes.c_char_p, _I)
+_sig(hip, "rtu_probe_kernel", _I, _P, _I)
+_sig(hip, "rtu_probe_read", _I, _P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_I))
 _sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
 _sig(hip, "rtu_debug_tail_from", _I, _P, _I)
 _sig(hip, "rtu_timeline_exits", _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double))
@@ -268,7 +285,7 @@ def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stat
     if rc != RTU_OK:
         raise RtuError(rc, "rtu_frame_setup")
     f.shard_rank, f.shard_count = shard_rank, shard_count
-    f.collect_stats = 1 if collect_stats else 0
+    f.collect_stats = int(collect_stats)  # False / True, or 2: touched-bytes mode of the fast variant
     f.max_bounce = max_bounce
     f.samples = samples  # 0: recipe W; S >= 1: recipe S (soft shadows, glossy bounces, depth of field)
     f.gather_bounces = gather_bounces  # 4 (with samples): recipe P, + the Monte-Carlo gather of config 5
@@ -360,6 +377,35 @@ class Context:
         ms = ctypes.c_float(0)
         self._check(hip.rtu_time_render(self._h, ctypes.byref(frame), d_ptr, stream, iters, ctypes.byref(ms)))
         return ms.value
+
+    def touched(self, textured=False):
+        """Touched-bytes mode (frame.collect_stats == 2): {kernel slot name: counters + 'bytes'} of the launches of the most
+        recent launch sequence that touched anything."""
+        arr = (RtuTouched * KERNEL_SLOTS)()
+        n = hip.rtu_get_touched(self._h, arr, KERNEL_SLOTS)
+        if n < 0:
+            self._check(n)
+        out = {}
+        for k in range(n):
+            d = arr[k].as_dict()
+            if any(d.values()):
+                d["bytes"] = int(hip.rtu_touched_bytes(ctypes.byref(arr[k]), 1 if textured else 0))
+                out[hip.rtu_kernel_slot_name(k).decode()] = d
+        return out
+
+    def probe_kernel(self, slot_name):
+        """Bracket every launch of that kernel slot ('k_trace2(L0)', ...; None: stop) with HIP events on its stream."""
+        slot = -1
+        if slot_name is not None:
+            names = [hip.rtu_kernel_slot_name(k).decode() for k in range(KERNEL_SLOTS)]
+            slot = names.index(slot_name)
+        self._check(hip.rtu_probe_kernel(self._h, slot))
+
+    def probe_read(self):
+        """(summed milliseconds, launches measured) since the last read; synchronises."""
+        ms, n = ctypes.c_float(0), _I(0)
+        self._check(hip.rtu_probe_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def stats(self):
         st = RtuStats()

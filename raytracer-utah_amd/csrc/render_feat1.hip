@@ -2,10 +2,9 @@
 // One translation unit per feature set so that the library builds in parallel (make -j).
 #include "render_impl.h"
 
-int rtu_launch_feat1(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode) {
-    (void)mode;
-    if (bvh_stack_needed <= 16) return launch_all<16, 1>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 24) return launch_all<24, 1>(args, n_tiles, stats, stream);
-    if (bvh_stack_needed <= 32) return launch_all<32, 1>(args, n_tiles, stats, stream);
-    return launch_all<RTU_MAX_BVH_STACK, 1>(args, n_tiles, stats, stream);
+int rtu_launch_feat1(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe) {
+    if (bvh_stack_needed <= 16) return launch_all<16, 1>(args, n_tiles, stats, stream, mode, probe);
+    if (bvh_stack_needed <= 24) return launch_all<24, 1>(args, n_tiles, stats, stream, mode, probe);
+    if (bvh_stack_needed <= 32) return launch_all<32, 1>(args, n_tiles, stats, stream, mode, probe);
+    return launch_all<RTU_MAX_BVH_STACK, 1>(args, n_tiles, stats, stream, mode, probe);
 }

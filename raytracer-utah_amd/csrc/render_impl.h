@@ -52,6 +52,11 @@ namespace {
 // bit 3: recipe P (with bit 1): the launches of the Monte-Carlo gather — chain tracing and the two Shade()
 // trees per chain hit, one of them lit by MonteCarlo()'s AmbientLight
 #define GID ((TEX & 8) != 0)
+// bit 4: touched-bytes mode (collect_stats == 2): the FAST variant's kernels — same trees, same culling, same two stages,
+// same images — counting per kernel launch what they read and write (Counters::t_*, RtuTouched in rtu_render.h). The
+// roofline of bench.py is computed from these counters, i.e. from the work the timed kernels themselves do.
+#define CNTD ((TEX & 16) != 0)
+#define RTU_BYTES(n) do { if (CNTD) cnt.t_bytes += (n); } while (0)
 
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
 // k_trace slot selection bits
@@ -124,6 +129,20 @@ __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counte
         if (lane_id() == 0 && v) atomicAdd(&a.counters[i], (unsigned long long)v);
     }
 }
+// touched-bytes mode: row `kid` (the launch's timeline slot) of the counter table. Must be reached by all 64 lanes.
+template <int TEX>
+__device__ __forceinline__ void flush_touched(const KernelArgs& a, const Counters& cnt, int kid) {
+    if (!CNTD) return;
+    unsigned vals[RTU_TOUCH_FIELDS] = {cnt.t_rays, cnt.t_node, cnt.t_meshbox, cnt.t_inner4, cnt.t_inner8, cnt.t_innerref, cnt.t_tri, cnt.t_win,
+                                       cnt.t_xform, cnt.t_bytes};
+#pragma unroll
+    for (int i = 0; i < RTU_TOUCH_FIELDS; i++) {
+        unsigned v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane_id() == 0 && v) atomicAdd(&a.counters[(size_t)kid * RTU_TOUCH_STRIDE + i], (unsigned long long)v);
+    }
+}
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
 template <int TEX>
@@ -157,7 +176,7 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
 // call; `want` says whether the lane has a frame. Returns the frame index or ~0u.
 template <int TEX>
 __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, uint32_t shard, uint32_t info, f3 p, f3 N, uint32_t fbw, f3 dir,
-                                                float fcw, f3 uvw) {
+                                                float fcw, f3 uvw, Counters& cnt) {
     const LevelBuffers& lv = a.lv[0];
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
     const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
@@ -179,6 +198,7 @@ __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, 
         const uint32_t fl = bf + (uint32_t)__popcll(mf & below);
         if (fl < lv.cap_s) {  // level 0 is sized for every root of the launch (ensure_levels): always true
             idx = fl + shard * lv.cap_s;
+            RTU_BYTES(48u + (TEXD ? 16u : 0u) + (wm ? 4u : 0u) + (wc ? 4u : 0u));
             if (TEXD) lv.fuv[idx] = make_float4(uvw.x, uvw.y, uvw.z, 0.0f);
             lv.fa[idx] = make_float4(p.x, p.y, p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(N.x, N.y, N.z, __uint_as_float(fbw));
@@ -316,7 +336,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             ray.p = mk3(hA.x, hA.y, hA.z);
             ray.dir = norm3(sampleOffset);  // :562
             smp.key = child_key(pkey, RTU_SLOT_GATHER);
-            bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+            bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
             if (!deferred && leader) {
                 const int hmid = hit ? as_const(s.nodes)[h.node].material_id : -1;
                 a.gi_h[ho] = make_float4(h.p.x, h.p.y, h.p.z, h.z);
@@ -346,15 +366,16 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (cam_origin + cam_u * ((float)x + ox)) + cam_v * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
         if (!deferred && leader) {
             if (!hit) {
                 f3 bg = background_sample<TEXD>(s, x, y);  // :145
                 a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
+                RTU_BYTES(16u);
             } else {
                 RTU_CNT(prim_hit);
                 mid = as_const(s.nodes)[h.node].material_id;
-                if (mid < 0) a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z);  // null material => white
+                if (mid < 0) { a.out[pix] = make_float4(1.0f, 1.0f, 1.0f, h.z); RTU_BYTES(16u); }  // null material => white
                 else want = true;
             }
             if (GID) {  // recipe P: the chain's depth-0 record instead of a frame; a null material stays white
@@ -369,7 +390,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     if (GID) return;
     uint32_t info = 0;
     if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
-    append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw);
+    append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
@@ -395,7 +416,9 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     bool deferred;
     primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
     if (!STATS) defer_push(a, 0, shard, deferred, pix);
+    if (deferred) RTU_BYTES(4u);
     flush_counters<STATS>(a, cnt);
+    flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY);
 }
 
 // Stage the top of every mesh's 8-wide tree (BFS order) into the workgroup's LDS node area.
@@ -428,12 +451,14 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
         const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        if (valid) RTU_BYTES(4u);
         int x, y;
         uint32_t sidx;
         pixel_of<TEX>(a, pix, x, y, sidx);
         bool deferred;
         primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + lane, cnt, deferred);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY2);
 }
 
 // stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
@@ -464,12 +489,14 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
         const bool valid = e < ns;
         uint32_t pix = 0;
         if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        if (valid && leader) RTU_BYTES(4u);
         int x, y;
         uint32_t sidx;
         pixel_of<TEX>(a, pix, x, y, sidx);
         bool deferred;
         primary_pixel<RTU_STACK8, false, false, true, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + grp, cnt, deferred, leader, RTU_COOP_GROUPS, s_nodes);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY2C);
 }
 
 // ---- one ray of one frame ------------------------------------------------------------------
@@ -481,6 +508,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const float4 fa = lv.fa[f];
+    if (leader) RTU_BYTES(16u);
     const uint32_t info = __float_as_uint(fa.w);
     const f3 p = mk3(fa.x, fa.y, fa.z);
     Ray r;
@@ -526,6 +554,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
             if (!(__float_as_uint(b1.w) & 1u)) return false;
         }
         const float4 fb = lv.fb[f], fc = lv.fc[f];
+        if (leader) RTU_BYTES(32u);
         const f3 N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
         r.dir = secondary_dir(sslot, info, dir, p, N, as_const(s.materials)[info & RTU_FI_MTL_MASK], frame_smp<TEX>(a, L, fb.w));
         RTU_CNT(sec);
@@ -533,9 +562,10 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     Hit h;
     fresh_hit(h, tmax);
     bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
+    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
     if (DEFER && deferred) return true;
     if (!leader) return false;
+    RTU_BYTES(is_shadow ? 4u : (TEXD ? 48u : 32u));
     if (is_shadow) {
         lv.fsh[(size_t)f * a.nsl + slot] = (hit && h.z > 0.0f) ? 0.0f : 1.0f;
     } else {
@@ -595,12 +625,15 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
         if (ns > lv.cap_s) ns = lv.cap_s;
         const bool active = e < ns;
         const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
+        if (active && list) RTU_BYTES(4u);
         const uint32_t f = shard * lv.cap_s + fl;
         bool deferred = false;
         if (active) deferred = frame_ray<STACK, STATS, !STATS, false, TEX>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
         if (!STATS) defer_push(a, ph, shard, deferred, (slot << 28) | f);
+        if (deferred) RTU_BYTES(4u);
     }
     flush_counters<STATS>(a, cnt);
+    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L);
 }
 
 // stage 2, long lists: one lane per deferred ray
@@ -621,8 +654,10 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
         const uint32_t e = k * 64u + lane;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        RTU_BYTES(4u);
         frame_ray<STACK, false, false, false, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + lane, cnt);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L + 2);
 }
 
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
@@ -649,8 +684,10 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
         const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        if (leader) RTU_BYTES(4u);
         frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L + 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -698,7 +735,7 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
 // a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
 template <bool STATS, int TEX>
 __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
-                                              uint32_t f, int st_out[3]) {
+                                              uint32_t f, int st_out[3], Counters& cnt) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const bool haveNext = L + 1 < RTU_MAX_LEVELS;
@@ -707,7 +744,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     f3 cam_pos = ld3(a.frame.cam_pos);
     st_out[0] = st_out[1] = st_out[2] = RTU_CH_NONE;
     float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
-    if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
+    if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; RTU_BYTES(TEXD ? 64u : 48u); }
     const uint32_t info = __float_as_uint(fa.w);
     const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
@@ -736,6 +773,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         if (info & RTU_FI_FRONT) direct = direct + mtl_color<TEXD>(s, (int)(info & RTU_FI_MTL_MASK), RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw) * ambI;
     }
     if (active && (info & RTU_FI_SH)) {
+        RTU_BYTES(4u * a.nsl);
         const int mtl = (int)(info & RTU_FI_MTL_MASK);
         const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
         const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
@@ -792,6 +830,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         s1[k] = s0[k];
         packed[k] = 0;
         if (slotActive) {
+            RTU_BYTES(32u);
             const float4* slotp = lv.fslot + ((size_t)f * 3 + k) * 2;
             s0[k] = slotp[0];
             s1[k] = slotp[1];
@@ -827,6 +866,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         else if (cmid < 0) st[k] = RTU_CH_WHITE;
         else if (spawn[k] && cfl[k] < nx.cap_s) {
             const uint32_t idx = cfl[k] + cshard * nx.cap_s;
+            RTU_BYTES(TEXD ? 80u : 48u);  // the child's record (textured: + its uvw, read from fsuv and written to fuv)
             // the child Shade(): ray direction, hit point and normal of the secondary ray
             const f3 cdir = secondary_dir(k, info, dir, p, N, m, smp);
             Smp csmp;
@@ -875,12 +915,14 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         for (int k = 0; k < 3; k++) {
             if (wantMain[k]) nx.lmain[(size_t)cshard * nx.cap_s + oa + (uint32_t)__popcll(am[k] & below)] = cfl[k];
             if (wantRefl[k]) nx.lrefl[(size_t)cshard * nx.cap_s + oc + (uint32_t)__popcll(cm[k] & below)] = cfl[k];
+            RTU_BYTES((wantMain[k] ? 4u : 0u) + (wantRefl[k] ? 4u : 0u));
             oa += (uint32_t)__popcll(am[k]);
             oc += (uint32_t)__popcll(cm[k]);
         }
         if (pending) lv.fpend[(size_t)shard * lv.cap_s + bp + (uint32_t)__popcll(pm & below)] = fl;
     }
     if (!active) return;
+    RTU_BYTES((pending ? 4u : 0u) + ((info & (RTU_FI_MAIN | RTU_FI_C)) ? 16u : 0u) + 16u);  // pending list, fchild, the result (pixel or fres)
     if (info & (RTU_FI_MAIN | RTU_FI_C)) lv.fchild[f] = make_int4(st[0], st[1], st[2], pending ? 1 : 0);
     if (!pending) {
         const f3 one = mk3(1, 1, 1);
@@ -901,19 +943,21 @@ __global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
     const uint32_t lane = threadIdx.x;
     const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
+    Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t fl = k * 64u + lane;
         const bool active = fl < shard_count(a, L, shard);
         int st[3];
-        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st);
+        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st, cnt);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L + 3);
 }
 
 // Frames that waited for children: combine bottom-up.
 // One frame that waited for its children (the body of k_combine; also used by k_tail).
 template <int TEX>
-__device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32_t f) {
+__device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32_t f, Counters& cnt) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const LevelBuffers& nx = a.lv[L + 1 < RTU_MAX_LEVELS ? L + 1 : L];
@@ -929,13 +973,16 @@ __device__ __forceinline__ void combine_frame(const KernelArgs& a, int L, uint32
     for (int k = 0; k < 3; k++) {
         ret[k] = mk3(1, 1, 1);
         if (st[k] >= 0) {
+            RTU_BYTES(16u);
             const float4 r = nx.fres[st[k]];
             ret[k] = mk3(r.x, r.y, r.z);
         }
     }
+    RTU_BYTES((TEXD ? 96u : 80u) + 16u);  // fa, fchild, fb, fc, fres (+ fuv); the result
     float bz = 0.0f;
     bool bfront = true;
     if ((info & RTU_FI_MAIN) && !(info & RTU_FI_TIR)) {
+        RTU_BYTES(32u);
         const float4* slotp = lv.fslot + ((size_t)f * 3 + SLOT_MAIN) * 2;
         bz = slotp[0].w;
         bfront = (__float_as_uint(slotp[1].w) & 2u) != 0;
@@ -965,13 +1012,16 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
         pmax = o > pmax ? o : pmax;
     }
     const uint32_t chunks = ((pmax + 63u) / 64u) * RTU_SHARDS;
+    Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t e = k * 64u + threadIdx.x;
         if (e >= a.fcnt->n_pending[L][shard]) continue;
         const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
-        combine_frame<TEX>(a, L, f);
+        RTU_BYTES(4u);
+        combine_frame<TEX>(a, L, f, cnt);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_COMBINE0 + L);
 }
 
 // THE TAIL. Deep recursion levels are often almost empty (two frames per level from level 3 on in
@@ -1027,7 +1077,7 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
                 const bool active = i < n;
                 const uint32_t f = active ? s_cur[L][i] : 0u;
                 int st[3];
-                consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st);
+                consume_frame<false, TEX>(a, L, lane, active, shard, shard, f - shard * a.lv[L].cap_s, f, st, cnt);
                 if (active) s_pend[L][i] = (st[0] >= 0 || st[1] >= 0 || st[2] >= 0) ? 1 : 0;
                 if (L + 1 < levels) {
 #pragma unroll
@@ -1052,10 +1102,11 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
             __threadfence();
             const uint32_t nL = s_n[L];
             for (uint32_t i = lane; i < nL; i += 64u)
-                if (s_pend[L][i]) combine_frame<TEX>(a, L, s_cur[L][i]);
+                if (s_pend[L][i]) combine_frame<TEX>(a, L, s_cur[L][i], cnt);
         }
         __threadfence();
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * Ls);
 }
 
 // ---- recipe P: MonteCarlo() of RenderFunctions.cpp:549-590 unrolled over the chain ---------------------
@@ -1118,14 +1169,25 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
             ia = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
             id = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
         }
-        const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw);
+        Counters cnt = {};
+        const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw, cnt);
         if (want && fa_idx != ~0u) a.lv[0].famb[fa_idx] = make_float4(amb.x, amb.y, amb.z, 0.0f);
-        append_root<TEX>(a, want, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw);
+        append_root<TEX>(a, want, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw, cnt);
     }
 }
 
+// One kernel of the sequence; `slot` is its timeline / counter-table slot. With a probe on that slot the launch is
+// bracketed by HIP events on the launch stream (bench.py: the dominant kernel's duration inside the timed region).
+#define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
+    do {                                                                                     \
+        const bool probed_ = probe && probe->slot == (kslot_);                               \
+        if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev0, stream);                   \
+        hipLaunchKernelGGL(kernel, grid, blk, 0, stream, __VA_ARGS__);                       \
+        if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev1, stream);                   \
+    } while (0)
+
 template <int STACK, int TEX>
-int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL) {
+int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL, const LaunchProbe* probe = nullptr) {
     const int levels = a.frame.max_bounce + 1;
     const dim3 block(64);
     // persistent grids (64-frame chunks are strided over them); an empty launch costs ~1 us per 4096
@@ -1135,15 +1197,16 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     const dim3 gridT(8192), gridN(32768), gridS(8192), gridF(4096), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     const dim3 gridP((n_tiles + 3) / 4);
+    if (CNTD) stats = false;  // the touched-bytes instantiations are the fast variant's (the reference-counting kernels are not built for them)
     if (mode == RTU_LAUNCH_SHADE) {
         hipLaunchKernelGGL((k_gi_roots<TEX>), gridN, block, 0, stream, a);
     } else if (stats) {
-        hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
+        if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
-        hipLaunchKernelGGL((k_primary<STACK, false, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
+        RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridP, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
-            hipLaunchKernelGGL((k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a);
-            hipLaunchKernelGGL((k_primary2<STACK, TEX>), gridN, block, 0, stream, a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), gridN, block, a);
         }
     }
     if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
@@ -1152,21 +1215,23 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     for (int L = 0; L < regular; L++) {
         const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
-            hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
-            if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
-            hipLaunchKernelGGL((k_consume<true, TEX>), gridF, block, 0, stream, a, L);
+            if constexpr (!CNTD) {
+                hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
+                if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
+                hipLaunchKernelGGL((k_consume<true, TEX>), gridF, block, 0, stream, a, L);
+            }
         } else {
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
-            hipLaunchKernelGGL((k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, 0, stream, a, L, sel, ph);
+            RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L, (k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, a, L, sel, ph);
             if (a.n_meshes) {
-                hipLaunchKernelGGL((k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), 0, stream, a, L, sel, ph);
-                hipLaunchKernelGGL((k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, 0, stream, a, L, sel, ph);
+                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a, L, sel, ph);
+                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, a, L, sel, ph);
             }
-            hipLaunchKernelGGL((k_consume<false, TEX>), gridF, block, 0, stream, a, L);
+            RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), gridF, block, a, L);
         }
     }
-    if (regular < levels) hipLaunchKernelGGL((k_tail<TEX>), dim3(8192), block, 0, stream, a, regular);
-    for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) hipLaunchKernelGGL((k_combine<TEX>), gridC, block, 0, stream, a, L);
+    if (regular < levels) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * regular, (k_tail<TEX>), dim3(8192), block, a, regular);
+    for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) RTU_LAUNCH(RTU_TL_COMBINE0 + L, (k_combine<TEX>), gridC, block, a, L);
     return (int)hipGetLastError();
 }
 

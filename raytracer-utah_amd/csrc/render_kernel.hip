@@ -168,29 +168,45 @@ int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed
 }
 
 
-int rtu_launch_feat0(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat1(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat2(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat3(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat4(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat5(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat10(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
-int rtu_launch_feat11(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode);
+int rtu_launch_feat0(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat1(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat2(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat3(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat4(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat5(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat10(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat11(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat16(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat17(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat20(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat21(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 
-int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode) {
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, int stats, hipStream_t stream, int mode, const LaunchProbe* probe) {
     // textured scenes, sampled frames and batches of frames run their own instantiations: the others carry no
     // uvw, sample nothing and draw nothing.
+    const bool ref = stats == 1;
     if (mode != RTU_LAUNCH_ALL) {
-        if (args.scene.textured) return rtu_launch_feat11(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        return rtu_launch_feat10(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+        if (stats == 2) return (int)hipErrorInvalidValue;
+        if (args.scene.textured) return rtu_launch_feat11(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        return rtu_launch_feat10(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
     }
-    switch ((args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0))) {
-        case 0: return rtu_launch_feat0(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        case 1: return rtu_launch_feat1(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        case 2: return rtu_launch_feat2(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        case 3: return rtu_launch_feat3(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        case 4: return rtu_launch_feat4(args, n_tiles, bvh_stack_needed, stats, stream, mode);
-        default: return rtu_launch_feat5(args, n_tiles, bvh_stack_needed, stats, stream, mode);
+    const int feat = (args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0));
+    if (stats == 2) {  // touched-bytes mode: recipe W, one frame or frames in flight
+        switch (feat) {
+            case 0: return rtu_launch_feat16(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            case 1: return rtu_launch_feat17(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            case 4: return rtu_launch_feat20(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            case 5: return rtu_launch_feat21(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            default: return (int)hipErrorInvalidValue;
+        }
+    }
+    switch (feat) {
+        case 0: return rtu_launch_feat0(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        case 1: return rtu_launch_feat1(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        case 2: return rtu_launch_feat2(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        case 3: return rtu_launch_feat3(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        case 4: return rtu_launch_feat4(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
+        default: return rtu_launch_feat5(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
     }
 }
 

@@ -56,7 +56,11 @@ struct RtuContext {
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
-    unsigned long long* counters = nullptr;  // 11 x u64
+    unsigned long long* counters = nullptr;  // 11 x u64 (RtuStats), or the touched-bytes table [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]
+    // probe: HIP events around the launches of one timeline slot (rtu_probe_kernel)
+    static const int kProbePairs = 64;
+    int probe_slot = -1, probe_used = 0;
+    hipEvent_t probe_ev[2 * kProbePairs] = {};
     struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
     std::vector<MeshInfo> mesh_info;
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
@@ -64,6 +68,8 @@ struct RtuContext {
 };
 
 namespace {
+
+const size_t kCounterBytes = (size_t)RTU_TL_KERNELS * RTU_TOUCH_STRIDE * sizeof(unsigned long long);
 
 int fail(RtuContext* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -512,6 +518,8 @@ int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
     if (f->samples < 0 || f->samples > 65536) return fail(ctx, RTU_ERR_ARG, "samples out of range");
     if (f->gather_bounces != 0 && (f->gather_bounces != RTU_GI_BOUNCES || f->samples < 1))
         return fail(ctx, RTU_ERR_ARG, "gather_bounces is 0 or %d (recipe P, with samples >= 1)", RTU_GI_BOUNCES);
+    if (f->collect_stats < 0 || f->collect_stats > 2) return fail(ctx, RTU_ERR_ARG, "collect_stats is 0, 1 or 2");
+    if (f->collect_stats == 2 && f->samples != 0) return fail(ctx, RTU_ERR_ARG, "the touched-bytes mode (collect_stats == 2) covers recipe W (samples == 0)");
     if (f->samples == 0 && ctx->has_scene && (ctx->scene_stochastic || f->dof != 0))
         return fail(ctx, RTU_ERR_STOCHASTIC, "the scene has %s: render it with frame.samples >= 1 (recipe S)",
                     ctx->scene_stochastic ? ctx->stochastic_what.c_str() : "depth of field");
@@ -627,8 +635,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
             ctx->gi_chains = chains;
         }
     }
-    bool stats = frame->collect_stats != 0;
-    if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, 11 * sizeof(unsigned long long), stream));
+    const int stats = frame->collect_stats;  // 0 fast, 1 reference counting, 2 touched bytes of the fast variant
+    if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kCounterBytes, stream));
     // the append counters start at zero; `overflow` is STICKY — launches only ever set it, check_overflow reads and clears
     // it — so that a frame that ran out of capacity is reported even when later launch sequences were queued behind it
     RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, offsetof(FrameCounters, overflow), stream));
@@ -647,7 +655,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
-    a.tail_from = stats ? RTU_MAX_LEVELS : ctx->tail_hint;
+    a.tail_from = stats == 1 ? RTU_MAX_LEVELS : ctx->tail_hint;
     if (frame->samples >= 1) {
         const float pixelIncrement = (float)(1.0 / frame->samples);  // RenderFunctions.cpp:68
         a.sampling = 1;
@@ -681,7 +689,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         a.gi_total = pixels * (uint32_t)batch;
     }
     ctx->last_tail_from = a.tail_from;
-    ctx->last_stats = stats;
+    ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
     if (gi_mode == RTU_LAUNCH_SHADE && gi_depth == 0) {
         hipError_t e0 = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
@@ -690,7 +698,15 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
         return RTU_OK;
     }
-    hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
+    LaunchProbe probe{-1, nullptr, nullptr};
+    const bool probing = ctx->probe_slot >= 0 && gi_mode == RTU_LAUNCH_ALL && ctx->probe_used < RtuContext::kProbePairs;
+    if (probing) {
+        probe.slot = ctx->probe_slot;
+        probe.ev0 = ctx->probe_ev[2 * ctx->probe_used];
+        probe.ev1 = ctx->probe_ev[2 * ctx->probe_used + 1];
+        ctx->probe_used++;
+    }
+    hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode, probing ? &probe : nullptr);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return RTU_OK;
 }
@@ -856,10 +872,10 @@ RtuContext* rtu_create_context(int device_id, int* err_out) {
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
-              hipMalloc((void**)&ctx->counters, 11 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&ctx->counters, kCounterBytes) == hipSuccess &&
               hipMalloc((void**)&ctx->fcnt, sizeof(FrameCounters)) == hipSuccess &&
               hipMemset(ctx->fcnt, 0, sizeof(FrameCounters)) == hipSuccess &&
-              hipMemset(ctx->counters, 0, 11 * sizeof(unsigned long long)) == hipSuccess;
+              hipMemset(ctx->counters, 0, kCounterBytes) == hipSuccess;
     if (!ok) {
         if (err_out) *err_out = RTU_ERR_HIP;
         rtu_destroy_context(ctx);
@@ -886,6 +902,8 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->probe_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1192,6 +1210,63 @@ int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     FrameCounters h;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     if (!h.overflow) learn_tail(ctx, h);
+    return RTU_OK;
+}
+
+int rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots) {
+    if (!ctx || !per_slot || n_slots < 1) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)RTU_TL_KERNELS * RTU_TOUCH_STRIDE);
+    RTU_HIP(ctx, hipMemcpy(h.data(), ctx->counters, kCounterBytes, hipMemcpyDeviceToHost));
+    static_assert(sizeof(RtuTouched) == RTU_TOUCH_FIELDS * sizeof(unsigned long long), "RtuTouched layout");
+    static_assert(RTU_KERNEL_SLOTS == RTU_TL_KERNELS, "slot count");
+    const int n = n_slots < RTU_TL_KERNELS ? n_slots : RTU_TL_KERNELS;
+    for (int k = 0; k < n; k++) memcpy(&per_slot[k], &h[(size_t)k * RTU_TOUCH_STRIDE], sizeof(RtuTouched));
+    return n;
+}
+
+unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured) {
+    if (!t) return 0;
+    return 48ull * t->node_tests + 24ull * t->mesh_box_tests + 84ull * t->xform_levels + 112ull * t->inner4 + 256ull * t->inner8 +
+           64ull * t->inner_ref + 64ull * t->tri_tests + (textured ? 148ull : 100ull) * t->winners + t->record_bytes;
+}
+
+const char* rtu_kernel_slot_name(int slot) {
+    static const char* const level_kernels[4] = {"k_trace", "k_trace2c", "k_trace2", "k_consume"};
+    static char buf[RTU_TL_KERNELS][24];
+    if (slot < 0 || slot >= RTU_TL_KERNELS) return "";
+    if (slot == 0) return "k_primary";
+    if (slot == 1) return "k_primary2c";
+    if (slot == 2) return "k_primary2";
+    if (slot < 3 + 4 * RTU_MAX_LEVELS) snprintf(buf[slot], sizeof buf[slot], "%s(L%d)", level_kernels[(slot - 3) % 4], (slot - 3) / 4);
+    else snprintf(buf[slot], sizeof buf[slot], "k_combine(L%d)", slot - (3 + 4 * RTU_MAX_LEVELS));
+    return buf[slot];
+}
+
+int rtu_probe_kernel(RtuContext* ctx, int slot) {
+    if (!ctx || slot >= RTU_TL_KERNELS) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    if (slot >= 0 && !ctx->probe_ev[0])
+        for (hipEvent_t& e : ctx->probe_ev) RTU_HIP(ctx, hipEventCreate(&e));
+    ctx->probe_slot = slot < 0 ? -1 : slot;
+    ctx->probe_used = 0;
+    return RTU_OK;
+}
+
+int rtu_probe_read(RtuContext* ctx, float* total_ms_out, int* launches_out) {
+    if (!ctx || !total_ms_out || !launches_out) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipDeviceSynchronize());
+    float total = 0;
+    for (int i = 0; i < ctx->probe_used; i++) {
+        float ms = 0;
+        RTU_HIP(ctx, hipEventElapsedTime(&ms, ctx->probe_ev[2 * i], ctx->probe_ev[2 * i + 1]));
+        total += ms;
+    }
+    *total_ms_out = total;
+    *launches_out = ctx->probe_used;
+    ctx->probe_used = 0;
     return RTU_OK;
 }
 

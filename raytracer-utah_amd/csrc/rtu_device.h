@@ -159,7 +159,9 @@ struct LevelBuffers {
 #define RTU_LDS_NODE_F4  ((RTU_LDS_BYTES - RTU_COOP_GROUPS * RTU_STACK8 * 4) / 16)
 
 #define RTU_SHARDS 64
-#define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_kernel.hip)
+#define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_impl.h)
+#define RTU_TOUCH_FIELDS 10  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
+#define RTU_TOUCH_STRIDE 16  // u64 per timeline slot in the counter table of the touched-bytes mode
 #define RTU_TL_ENDS 8192u   // exit-stamp slots per kernel (wavefront index modulo; a later wavefront overwrites an earlier one)
 #define RTU_TL_STRIDE (64u + RTU_TL_ENDS)
 
@@ -187,7 +189,7 @@ struct KernelArgs {
     uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
     uint32_t     defer_cap_s;
     uint32_t     pad0;
-    unsigned long long* counters;   // 11 x u64 (RtuStats order) or nullptr
+    unsigned long long* counters;   // 11 x u64 (RtuStats order); touched-bytes mode: [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]; or nullptr
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights
     int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
@@ -219,7 +221,15 @@ struct KernelArgs {
 #define RTU_LAUNCH_CHAIN 1
 #define RTU_LAUNCH_SHADE 2
 #define RTU_GI_BOUNCES   4   // monteCarloBounces, RenderFunctions.cpp:31
-int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL);
+// stats: 0 the fast variant, 1 the reference-counting variant (RtuStats), 2 the fast variant in touched-bytes mode (RtuTouched;
+// recipe W only). probe (may be NULL): bracket the launch in timeline slot `slot` with the two HIP events.
+struct LaunchProbe {
+    int   slot;
+    void* ev0;
+    void* ev1;
+};
+int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, int stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL,
+                     const LaunchProbe* probe = nullptr);
 int rtu_launch_gi_final(const KernelArgs& args, hipStream_t stream);
 
 // recipe S: add one sample's image to the accumulators / write the mean

@@ -37,9 +37,15 @@ __device__ __forceinline__ void fresh_hit(Hit& h, float tmax) {  // HitInfo::Ini
 
 struct Counters {
     unsigned prim, prim_hit, sec, shd, node, mesh, inner, leafv, leafe, tri, acc;
+    // touched-bytes mode of the FAST variant (collect_stats == 2, RtuTouched in rtu_render.h): what the timed
+    // kernels themselves read and write — their own trees, their own culling, their own two stages
+    unsigned t_rays, t_node, t_meshbox, t_inner4, t_inner8, t_innerref, t_tri, t_win, t_xform, t_bytes;
 };
 
 #define RTU_CNT(field) do { if (STATS) cnt.field++; } while (0)
+// FC: the instantiation counts what it touches; `fc_lane`: this lane does the counting (one lane of the eight that share
+// a ray in the cooperative kernels)
+#define RTU_TOUCH(field, n) do { if (FC && fc_lane) cnt.field += (n); } while (0)
 
 // ---------------------------------------------------------------------------
 // Node::ToNodeCoords (scene.h:501-507): p' = itm*(p-pos); d' = itm*((p+d)-pos) - p'
@@ -405,9 +411,10 @@ __device__ __forceinline__ int tri_hit(const TriRec& T, uint32_t slot, const Ray
 //    margin that covers the rounding of the slab and triangle arithmetic (see
 //    DESIGN.md "Culling margin"): every triangle in it would fail `t < hInfo.z`
 //    (objFunctions.cpp:270), so skipping it cannot change any output bit.
-template <int STACK, bool STATS, bool CULL, bool TIE>
+template <int STACK, bool STATS, bool CULL, bool TIE, bool FC = false>
 __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const float4* bvh, const float4* tris, const uint32_t* elements,
-                                          const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, const uint32_t stride, bool& tie) {
+                                          const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, const uint32_t stride, bool& tie,
+                                          const bool fc_lane = true) {
     // The reference's slab test has special cases for an exactly-zero direction component
     // (objFunctions.cpp:154-216). If ANY lane of the wavefront has one, the whole wavefront
     // takes the literal four-branch form; otherwise the branch-free reciprocal form.
@@ -430,6 +437,7 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
     while (alive) {
         while (alive && count == 0) {  // inner nodes
             RTU_CNT(inner);
+            RTU_TOUCH(t_innerref, 1);
             const float4* pair = bvh + 2 * index;  // children index, index+1: one 64-byte line
             float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
             float e1, x1, e2, x2;
@@ -483,6 +491,7 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
         if (alive) {  // leaf: :394-396; the next record is fetched while the current one is tested
             RTU_CNT(leafv);
             if (STATS) cnt.leafe += count;
+            RTU_TOUCH(t_tri, count);
             TriRec cur = load_tri(tris, index);
             for (uint32_t i = 0; i < count; i++) {
                 TriRec nxt = cur;
@@ -507,6 +516,7 @@ __device__ __forceinline__ bool mesh_walk(const RTU_CONST DevMesh& mesh, const f
     }
     if (hitResult && !shadow && !(TIE && tie)) {
         // hInfo.N / hInfo.p of the winning triangle (:322, :324)
+        RTU_TOUCH(t_win, 1);
         const uint32_t face = elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
@@ -561,9 +571,10 @@ __device__ __forceinline__ bool fast_box(const FastRay& f, float4 lo, float4 hi,
 // The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
 // the order only affects speed: an exact tie between two accepted triangles, the one case where
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
-template <int STACK, class MeshT>
+template <int STACK, bool FC = false, class MeshT>
 __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                                const uint32_t stride, bool& tie, const uint32_t stackLimit) {
+    const bool fc_lane = true;
     const int slim = (int)(stackLimit < (uint32_t)STACK ? stackLimit : (uint32_t)STACK);
     // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches.
     const float4* bvh4 = mesh.bvh4;
@@ -580,6 +591,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
     bool alive = true;
     while (alive) {
         while (alive && count == 0) {  // inner nodes
+            RTU_TOUCH(t_inner4, 1);
             const float4* nd = bvh4 + (size_t)index * 8u;
             const float4 nx = nd[onx], ny = nd[ony], nz = nd[onz], fx = nd[ofx], fy = nd[ofy], fz = nd[ofz], rf = nd[6];
             const float inf = __builtin_inff();
@@ -622,6 +634,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
             count = next >> 28;
         }
         if (alive) {  // leaf; the next record is fetched while the current one is tested
+            RTU_TOUCH(t_tri, count);
             TriRec cur = load_tri(tris, index);
             for (uint32_t i = 0; i < count; i++) {
                 TriRec nxt = cur;
@@ -645,6 +658,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
         }
     }
     if (hitResult && !shadow && !tie) {
+        RTU_TOUCH(t_win, 1);
         const uint32_t face = mesh.fast.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
@@ -655,7 +669,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
 
 // The counting variant walks the reference's tree; the fast variant walks the SAH tree and
 // falls back to the reference's on an exact tie (see DevMesh).
-template <int STACK, bool STATS, bool CULL>
+template <int STACK, bool STATS, bool CULL, bool FC = false>
 __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                          const uint32_t stackLimit, const uint32_t stride = 64) {
     if (!box_hit(ray, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) return false;
@@ -663,11 +677,11 @@ __device__ __forceinline__ bool mesh_hit(const RTU_CONST DevMesh& mesh, const Ra
     bool tie = false;
     if (!CULL) return mesh_walk<STACK, STATS, false, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, tie);
     const Hit h0 = h;
-    bool r = mesh_walk_fast<STACK>(mesh, ray, shadow, h, stk, cnt, stride, tie, stackLimit);
+    bool r = mesh_walk_fast<STACK, FC>(mesh, ray, shadow, h, stk, cnt, stride, tie, stackLimit);
     if (tie) {  // rare: two accepted triangles with bitwise-equal t — the reference's test order decides
         h = h0;
         bool t2 = false;
-        r = mesh_walk<STACK, STATS, CULL, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2);
+        r = mesh_walk<STACK, STATS, CULL, false, FC>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2);
     }
     return r;
 }
@@ -697,9 +711,10 @@ __device__ __forceinline__ int grp_xor(int v) {  // value of lane ^ M
 }
 
 // The caller has established that the ray passes the mesh's bounding box.
-template <int STACK, bool CULL, class MeshT>
+template <int STACK, bool CULL, bool FC = false, class MeshT>
 __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                               const uint32_t stride, const float4* lds_nodes, const uint32_t stackLimit) {
+    const bool fc_lane = (threadIdx.x & 7u) == 0;  // eight lanes share the ray: one of them counts
     const uint32_t slim = stackLimit < (uint32_t)RTU_STACK8 ? stackLimit : (uint32_t)RTU_STACK8;
     const Hit h0 = h;
     bool tie = false;
@@ -718,6 +733,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
     bool alive = true;
     while (alive) {
         while (alive && count == 0) {  // inner node: lane `sub` tests child `sub`
+            RTU_TOUCH(t_inner8, 1);
             const float4* nd = (index < ldsN ? lds_nodes + ldsOff : bvh8) + ((size_t)index * 8u + sub) * 2u;
             const float4 c0 = nd[0], c1 = nd[1];
             float tn;
@@ -762,6 +778,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
             myWin.slot = index + sub;
             myWin.bc = mk3(0, 0, 0);
             if (sub < count) {
+                if (FC) cnt.t_tri++;  // every lane tests its own triangle
                 const TriRec T = load_tri(tris, index + sub);
                 Hit hl = h;  // test against the best BEFORE this leaf; the reduction below applies the order
                 const int code = tri_hit<false, true>(T, index + sub, ray, hl, myWin, cnt);
@@ -815,9 +832,10 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
     if (tie) {  // redo this ray on the reference's tree, one lane per ray (all eight lanes identically)
         h = h0;
         bool t2 = false;
-        return mesh_walk<STACK, false, CULL, false>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2);
+        return mesh_walk<STACK, false, CULL, false, FC>(mesh, mesh.ref.bvh, mesh.ref.tri, mesh.ref.elements, ray, shadow, h, stk, cnt, stride, t2, fc_lane);
     }
     if (hitResult && !shadow) {
+        RTU_TOUCH(t_win, 1);
         const uint32_t face = mesh.fast.elements[win.slot];
         h.N = norm3(interp(mesh.vn, mesh.fn + 3 * face, win.bc));
         h.p = interp(mesh.v, mesh.f + 3 * face, win.bc);
@@ -841,9 +859,11 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 // the bounding box of a mesh node the walk is abandoned and `deferred` is set; the caller
 // queues the ray for the narrow-wavefront stage-2 kernel, which walks the whole scene
 // again with DEFER=false. Rays that never touch a mesh complete in stage 1.
-template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false>
+template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
                                       const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
+    const bool fc_lane = !COOP || (threadIdx.x & 7u) == 0;
+    RTU_TOUCH(t_rays, 1);
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
     const RTU_CONST DevMesh* meshes = as_const(s.meshes);
     bool any = false;
@@ -874,6 +894,8 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         }
         Ray lr = to_node(n, pr);
         RTU_CNT(node);
+        RTU_TOUCH(t_node, 1);
+        if (n.obj_type == RTU_OBJ_TRIMESH) RTU_TOUCH(t_meshbox, 1);
         bool hit;
         if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h, TEX);
         else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h, TEX);
@@ -884,9 +906,9 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         } else if (COOP) {
             const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
             hit = box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT) &&  // TriObj::IntersectRay's own box test (:335)
-                  mesh_hit_coop<STACK, CULL>(mesh, lr, shadow, h, stk, cnt, stride, lds_nodes, s.walk_stack_limit);
+                  mesh_hit_coop<STACK, CULL, FC>(mesh, lr, shadow, h, stk, cnt, stride, lds_nodes, s.walk_stack_limit);
         } else {
-            hit = mesh_hit<STACK, STATS, CULL>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, s.walk_stack_limit);
+            hit = mesh_hit<STACK, STATS, CULL, FC>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, s.walk_stack_limit);
         }
         if (hit) {
             any = true;
@@ -902,7 +924,10 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         h.p = lp;
         h.N = lN;
         const DevNode* gn = s.nodes;  // per-lane node index: ordinary loads
-        for (int j = best; j >= 0; j = gn[j].parent) from_node(gn[j], h);
+        for (int j = best; j >= 0; j = gn[j].parent) {
+            RTU_TOUCH(t_xform, 1);
+            from_node(gn[j], h);
+        }
     }
     return any;
 }

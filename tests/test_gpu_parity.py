@@ -44,7 +44,11 @@ def check_against(gpu, ref_rgbz, orc, rel_tol=RGB_REL_TOL):
     d8 = np.abs(g8.astype(np.int32) - c8.astype(np.int32))
     assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
     a, b = gpu[..., :3].astype(np.float64), ref_rgbz[..., :3].astype(np.float64)
-    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    # the reference's own arithmetic yields NaN colours on some inputs (tests/scenes/multimtl: 1029 pixels); they are
+    # results like any other: the same pixels must be NaN on both sides, the rest is compared by value
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan), "NaN colours at different pixels"
+    rel = (np.abs(a - b) / np.maximum(np.abs(b), 1e-3))[~nan]
     assert rel.max() <= rel_tol, "linear RGB relative error %.3g" % rel.max()
     return int((d8 > 0).sum())
 
@@ -629,3 +633,57 @@ def test_pack_image_matches_the_host_postprocess(pkg, orc, ctx, golden):
         assert sha256(z) == g.meta["sha256_z_f32"]
         for p_ in (d, dz, drgb):
             pkg.hip.rtu_device_free(ctx._h, p_)
+
+
+@pytest.mark.parametrize("tag,fif", [("teapot2_240x135", 1), ("p11_240x135", 1), ("p4_240x135", 1), ("p7_200x150", 1), ("teapot2_240x135", 4),
+                                     ("p13_200x150", 3)])
+def test_touched_bytes_mode_is_the_fast_variant_counting_itself(pkg, ctx, golden, tag, fif):
+    """collect_stats == 2 (what bench.py's roofline is computed from): the kernels of the FAST variant — same trees, same
+    culling, same two stages — with per-kernel counters of what they touch. Its images are the fast variant's bit for bit, its
+    ray bookkeeping adds up (every pixel starts one walk in k_primary; stage 2 restarts exactly the deferred ones), and it walks
+    fewer boxes than the reference-counting variant (whose counters equal the oracle's)."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    textured = scene.desc.n_textures > 0
+    cams = []
+    for i in range(fif):
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        cam.pos[0] += 0.4 * i
+        cams.append(cam)
+    fast = [ctx.render(pkg.frame_setup(c, W, H))[0] for c in cams]
+    d = pkg.hip.rtu_device_alloc(ctx._h, fif * W * H * 16)
+    frames = [pkg.frame_setup(c, W, H, collect_stats=2) for c in cams]
+    for coop in (1, 10 ** 9):  # one lane per ray / eight lanes per ray in stage 2
+        for f in frames:
+            f.coop_threshold = coop
+        if fif == 1:
+            ctx.render_device(frames[0], d, None)
+        else:
+            ctx.render_frames_device(frames, d, None)
+        ctx.frame_status()
+        t = ctx.touched(textured)
+        out = np.empty((fif, H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+        for i in range(fif):
+            assert np.array_equal(out[i].view(np.uint32), fast[i].view(np.uint32)), "touched-bytes mode changed the image"
+        _, deferred = ctx.frame_counts()
+        assert t["k_primary"]["rays"] == fif * W * H
+        st2 = t.get("k_primary2", {"rays": 0})["rays"] + t.get("k_primary2c", {"rays": 0})["rays"]
+        assert st2 == deferred[0]
+        assert ("k_primary2" in t) != ("k_primary2c" in t) or deferred[0] == 0
+        assert t["k_primary"]["record_bytes"] >= 16 * (fif * W * H - deferred[0])  # a pixel or a frame record per finished pixel
+        for name, c in t.items():
+            assert c["bytes"] >= c["record_bytes"] and c["bytes"] > 0, name
+            if name.startswith(("k_consume", "k_combine")):
+                assert c["rays"] == 0 and c["bytes"] == c["record_bytes"]
+            if name.startswith("k_trace2(") or name == "k_primary2":
+                assert c["inner8"] == 0
+            if name.startswith("k_trace2c") or name == "k_primary2c":
+                assert c["inner4"] == 0
+    pkg.hip.rtu_device_free(ctx._h, d)
+    if scene.desc.n_meshes and fif == 1:
+        _, ref = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+        inner = sum(c["inner4"] + c["inner8"] + c["inner_ref"] for c in t.values())
+        assert 0 < inner < ref["inner_visits"]

@@ -231,7 +231,7 @@ unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured);
 const char* rtu_kernel_slot_name(int slot);
 
 /* Measurement helper for bench.py: bracket every launch of the kernel in `slot` with HIP events on the launch stream, from now on
- * (slot < 0: stop). rtu_probe_read synchronises, returns the summed duration and the number of launches measured since the last
+ * (slot < 0: stop; what was measured stays until it is read). rtu_probe_read synchronises, returns the summed duration and the number of launches measured since the last
  * read (at most 64 are kept) and starts over. Recipe W launch sequences only. */
 int  rtu_probe_kernel(RtuContext* ctx, int slot);
 int  rtu_probe_read(RtuContext* ctx, float* total_ms_out, int* launches_out);

@@ -31,6 +31,8 @@ lib.rtu_oracle_render_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_i
 lib.rtu_oracle_render.restype = ctypes.c_int
 lib.rtu_oracle_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.POINTER(OracleStats), ctypes.c_int]
+lib.rtu_oracle_render_scheduled.restype = ctypes.c_int
+lib.rtu_oracle_render_scheduled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 lib.rtu_oracle_camera_frame.restype = ctypes.c_int
 lib.rtu_oracle_camera_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 lib.rtu_oracle_postprocess.restype = None
@@ -67,6 +69,17 @@ def render(scene, width, height, threads=1, row0=0, nrows=None):
     out = np.empty((nrows, width, 4), np.float32)
     st = OracleStats()
     rc = lib.rtu_oracle_render_rows(scene.desc_ptr, width, height, row0, nrows, out.ctypes.data, ctypes.byref(st), threads)
+    if rc != 0:
+        raise OracleError(rc)
+    return out, st.as_dict()
+
+
+def render_scheduled(scene, width, height, threads, per_pixel):
+    """Recipe W, whole frame; per_pixel: the reference's PixelIterator schedule (one atomic fetch per pixel,
+    PixelIterator.h:25-38) instead of chunks of rows. Same image, different scaling."""
+    out = np.empty((height, width, 4), np.float32)
+    st = OracleStats()
+    rc = lib.rtu_oracle_render_scheduled(scene.desc_ptr, width, height, out.ctypes.data, ctypes.byref(st), threads, 1 if per_pixel else 0)
     if rc != 0:
         raise OracleError(rc)
     return out, st.as_dict()

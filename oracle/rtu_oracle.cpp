@@ -831,6 +831,8 @@ struct Sampling {
     int spp;          // 0: recipe W (one ray through the pixel centre); S >= 1: recipe S, the sample loop of Render()
     bool sequential, libm_trig;
     bool gi;          // recipe P: recipe S plus the Monte-Carlo gather of Render() (:129-134)
+    bool per_pixel;   // work distribution: false = chunks of rows; true = the reference's PixelIterator (PixelIterator.h:25-38):
+                      // one shared atomic counter, ONE PIXEL per fetch, x = i % W, y = i / W
 };
 
 void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::atomic<int>* next_row, int y_begin,
@@ -846,11 +848,19 @@ void render_rows(const RtuSceneDesc* s, const CamFrame& cf, int W, int H, std::a
     const V3 right = normalized(cross(normalized(ld3(s->camera.dir)), normalized(up)));
     const LightSet scene_lights = {s->lights, s->n_lights};
     for (;;) {
-        int y0 = next_row->fetch_add(chunk);
-        if (y0 >= y_end) break;
-        int y1 = y0 + chunk < y_end ? y0 + chunk : y_end;
+        int y0, y1, x0 = 0, x1 = W;
+        if (sm.per_pixel) {  // next_row counts pixels from y_begin * W
+            const int i = next_row->fetch_add(1);
+            if (i >= y_end * W) break;
+            y0 = i / W; y1 = y0 + 1;
+            x0 = i % W; x1 = x0 + 1;
+        } else {
+            y0 = next_row->fetch_add(chunk);
+            if (y0 >= y_end) break;
+            y1 = y0 + chunk < y_end ? y0 + chunk : y_end;
+        }
         for (int y = y0; y < y1; y++) {
-            for (int x = 0; x < W; x++) {
+            for (int x = x0; x < x1; x++) {
                 float* o = rgbz + 4 * ((size_t)(y - y_begin) * W + x);
                 if (sm.spp == 0) {
                     // recipe W: CalculateCurrentPoint(x,y,0.5f,0.5f,org), RenderFunctions.cpp:258-268
@@ -951,10 +961,10 @@ static int render_impl(const RtuSceneDesc* scene, int width, int height, int row
     if (width <= 0 || height <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > height || !rgbz_out || sm.spp < 0) return RTU_ORACLE_ERR_ARG;
     if (threads < 1) threads = 1;
     CamFrame cf = camera_frame(scene->camera, width, height);
-    std::atomic<int> next(row0);
+    std::atomic<int> next(sm.per_pixel ? row0 * width : row0);
     std::vector<RtuOracleStats> st(threads);
     int chunk = 4;
-    if (threads == 1) {
+    if (threads == 1 && !sm.per_pixel) {
         render_rows(scene, cf, width, height, &next, row0, row0 + nrows, nrows > 0 ? nrows : 1, rgbz_out, &st[0], sm);
     } else {
         std::vector<std::thread> th;
@@ -971,7 +981,7 @@ static int render_impl(const RtuSceneDesc* scene, int width, int height, int row
 
 int rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, float* rgbz_out,
                            RtuOracleStats* stats, int threads) {
-    Sampling sm = {0, false, false, false};
+    Sampling sm = {0, false, false, false, false};
     return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
 }
 
@@ -980,7 +990,7 @@ int rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height, 
     if (spp < 1 || (stream != RTU_ORACLE_STREAM_KEYED && stream != RTU_ORACLE_STREAM_SEQUENTIAL) ||
         (trig != RTU_ORACLE_TRIG_PORTABLE && trig != RTU_ORACLE_TRIG_LIBM))
         return RTU_ORACLE_ERR_ARG;
-    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, false};
+    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, false, false};
     return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
 }
 
@@ -989,7 +999,7 @@ int rtu_oracle_render_paths(const RtuSceneDesc* scene, int width, int height, in
     if (spp < 1 || (stream != RTU_ORACLE_STREAM_KEYED && stream != RTU_ORACLE_STREAM_SEQUENTIAL) ||
         (trig != RTU_ORACLE_TRIG_PORTABLE && trig != RTU_ORACLE_TRIG_LIBM))
         return RTU_ORACLE_ERR_ARG;
-    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, true};
+    Sampling sm = {spp, stream == RTU_ORACLE_STREAM_SEQUENTIAL, trig == RTU_ORACLE_TRIG_LIBM, true, false};
     return render_impl(scene, width, height, row0, nrows, rgbz_out, stats, threads, sm);
 }
 
@@ -1006,6 +1016,12 @@ void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* co
 uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx) { return rand31(key, idx); }
 uint32_t rtu_oracle_sample_key(uint32_t pixel, uint32_t sample) { return sample_key(pixel, sample); }
 uint32_t rtu_oracle_child_key(uint32_t key, uint32_t slot) { return child_key(key, slot); }
+
+int rtu_oracle_render_scheduled(const RtuSceneDesc* scene, int width, int height, float* rgbz_out, RtuOracleStats* stats, int threads,
+                                int per_pixel_schedule) {
+    Sampling sm = {0, false, false, false, per_pixel_schedule != 0};
+    return render_impl(scene, width, height, 0, height, rgbz_out, stats, threads, sm);
+}
 
 int rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* rgbz_out, RtuOracleStats* stats, int threads) {
     return rtu_oracle_render_rows(scene, width, height, 0, height, rgbz_out, stats, threads);

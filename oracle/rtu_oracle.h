@@ -34,6 +34,10 @@ int  rtu_oracle_render_rows(const RtuSceneDesc* scene, int width, int height, in
                             float* rgbz_out, RtuOracleStats* stats, int threads);
 int  rtu_oracle_render(const RtuSceneDesc* scene, int width, int height, float* rgbz_out,
                        RtuOracleStats* stats, int threads);
+/* The whole frame with the work distribution chosen: 0 = chunks of four rows per fetch (what the other entry points do),
+ * 1 = the reference's PixelIterator (PixelIterator.h:25-38): one shared atomic counter, one pixel per fetch. Same image. */
+int  rtu_oracle_render_scheduled(const RtuSceneDesc* scene, int width, int height, float* rgbz_out,
+                                 RtuOracleStats* stats, int threads, int per_pixel_schedule);
 /* Recipe S (row f1): spp samples per pixel as in the sample loop of Render() (RenderFunctions.cpp:73-152:
  * Halton pixel offsets, depth of field, soft shadows, glossy bounces), direct lighting only; rgb = mean
  * of the samples, z = mean hInfo.z of the samples that hit. stream: where the integers that replace

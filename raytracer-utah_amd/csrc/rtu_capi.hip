@@ -1250,7 +1250,7 @@ int rtu_probe_kernel(RtuContext* ctx, int slot) {
     if (slot >= 0 && !ctx->probe_ev[0])
         for (hipEvent_t& e : ctx->probe_ev) RTU_HIP(ctx, hipEventCreate(&e));
     ctx->probe_slot = slot < 0 ? -1 : slot;
-    ctx->probe_used = 0;
+    if (slot >= 0) ctx->probe_used = 0;  // stopping keeps what was measured until it is read
     return RTU_OK;
 }
 

@@ -254,3 +254,14 @@ def test_recipe_p_keyed_stream_is_the_same_estimator(pkg, orc, golden):
         return x[:h, :w, :3].reshape(h // 8, 8, w // 8, 8, 3).mean((1, 3))
     ba, bb = blocks(a), blocks(b)
     assert np.abs(ba - bb).sum() / np.abs(ba).sum() < 0.08
+
+
+def test_per_pixel_schedule_renders_the_same_image(pkg, orc, golden):
+    """bench.py times the CPU port under both work distributions: the reference's PixelIterator
+    (one atomic fetch per pixel) and chunks of rows. Scheduling must not change a bit."""
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    a, sa = orc.render(scene, g.width, g.height, threads=4)
+    for threads in (1, 5):
+        b, sb = orc.render_scheduled(scene, g.width, g.height, threads, True)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa == sb

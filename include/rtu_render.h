@@ -192,6 +192,11 @@ int  rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_
  * This sets it for the next frame: 1..5, or 6 for "no tail". */
 int  rtu_debug_tail_from(RtuContext* ctx, int level);
 
+/* Test hook: switch the node-level bounds of the fast variant off (0) or on (1, the default after an upload) until the next
+ * upload: the world-space box per scene node and, for primary rays, its screen rectangle per camera, by which a ray skips
+ * nodes it cannot touch before their transformation and exact test. Results must not change. */
+int  rtu_debug_node_bounds(RtuContext* ctx, int on);
+
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
  * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would
  * need more is finished on the reference's tree — on any scene. Results must not change. */
@@ -215,7 +220,7 @@ int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
  * "k_primary", "k_primary2c", "k_primary2", "k_trace(L0)", "k_trace2c(L0)", "k_trace2(L0)", "k_consume(L0)", ..., "k_combine(L0)", ...;
  * the tail kernel reports in the k_trace slot of its cut level). The images of this mode are those of the fast variant, bit for bit.
  * ALGORITHMIC bytes of a launch (rtu_touched_bytes; cache-agnostic, every access counted where it is made):
- *   48 node_tests (itm + pos) + 24 mesh_box_tests (bounding box) + 84 xform_levels (tm + pos + itm of FromNodeCoords)
+ *   24 bound_tests (a node's world-space box) + 48 node_tests (itm + pos) + 24 mesh_box_tests (bounding box) + 84 xform_levels (tm + pos + itm of FromNodeCoords)
  *   + 112 inner4 (7 float4 of a 4-wide node) + 256 inner8 (8 x 32 B child records) + 64 inner_ref (a sibling pair of the reference's
  *   tree: exact-tie / stack-overflow fallback) + 64 tri_tests (triangle record) + 100 winners (element, face and normal indices, three
  *   vertices, three normals; 148 with texture vertices) + record_bytes (frame records, lists, shadow results, pixels: counted at
@@ -225,6 +230,7 @@ typedef struct RtuTouched {
     uint64_t rays;            /* Trace / ShadowTrace walks started by this launch */
     uint64_t node_tests, mesh_box_tests, inner4, inner8, inner_ref, tri_tests, winners, xform_levels;
     uint64_t record_bytes;
+    uint64_t bound_tests;     /* node-level bounds tested (24 B each: the node's world-space box) */
 } RtuTouched;
 int         rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots);   /* synchronises; returns the slots written */
 unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured);

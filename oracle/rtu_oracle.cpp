@@ -963,7 +963,10 @@ static int render_impl(const RtuSceneDesc* scene, int width, int height, int row
     CamFrame cf = camera_frame(scene->camera, width, height);
     std::atomic<int> next(sm.per_pixel ? row0 * width : row0);
     std::vector<RtuOracleStats> st(threads);
-    int chunk = 4;
+    // rows per fetch: four, fewer when there are so many threads that four-row chunks would leave each of them one or two
+    // (256 threads on 1080 rows: single rows, about four per thread, so that the expensive rows spread out)
+    int chunk = nrows / (threads * 4);
+    chunk = chunk < 1 ? 1 : chunk > 4 ? 4 : chunk;
     if (threads == 1 && !sm.per_pixel) {
         render_rows(scene, cf, width, height, &next, row0, row0 + nrows, nrows > 0 ? nrows : 1, rgbz_out, &st[0], sm);
     } else {

@@ -134,7 +134,7 @@ template <int TEX>
 __device__ __forceinline__ void flush_touched(const KernelArgs& a, const Counters& cnt, int kid) {
     if (!CNTD) return;
     unsigned vals[RTU_TOUCH_FIELDS] = {cnt.t_rays, cnt.t_node, cnt.t_meshbox, cnt.t_inner4, cnt.t_inner8, cnt.t_innerref, cnt.t_tri, cnt.t_win,
-                                       cnt.t_xform, cnt.t_bytes};
+                                       cnt.t_xform, cnt.t_bytes, cnt.t_bounds};
 #pragma unroll
     for (int i = 0; i < RTU_TOUCH_FIELDS; i++) {
         unsigned v = vals[i];
@@ -366,7 +366,19 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (cam_origin + cam_u * ((float)x + ox)) + cam_v * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes);
+        // node-level bounds of a primary ray: the pixel against every node's screen rectangle for this camera (k_node_rects)
+        unsigned long long skip = 0;
+        const bool rects = !STATS && !SMPD && a.node_rects != nullptr;
+        if (rects) {
+            const RTU_CONST int* rc = as_const(reinterpret_cast<const int*>(a.node_rects)) + 4u * (size_t)sidx * s.n_nodes;  // wave-uniform: scalar loads
+            const uint32_t nn = s.n_nodes < 64u ? s.n_nodes : 64u;
+            for (uint32_t k = 0; k < nn; k++) {
+                const int x0 = rc[4u * k], y0 = rc[4u * k + 1u], x1 = rc[4u * k + 2u], y1 = rc[4u * k + 3u];
+                if (x < x0 || x >= x1 || y < y0 || y >= y1) skip |= 1ull << k;
+            }
+            if (CNTD && leader) cnt.t_bytes += 16u * nn;
+        }
+        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes, skip, rects);
         if (!deferred && leader) {
             if (!hit) {
                 f3 bg = background_sample<TEXD>(s, x, y);  // :145
@@ -1176,6 +1188,55 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
     }
 }
 
+// NODE-LEVEL BOUNDS of primary rays (recipe W): per camera of the launch and per node, the rectangle of pixels whose
+// primary ray can come within the cull margin of the node's world-space bound — the eight corners of the bound, widened by
+// delta = 1e-4 * max(scene scale, |camera|), projected through the camera in binary64, two pixels of slack on every side.
+// A corner at or behind the camera plane makes the rectangle the whole image. One lane per (camera, node).
+__global__ void __launch_bounds__(64) k_node_rects(KernelArgs a, uint32_t entries) {
+    const uint32_t n_nodes = a.scene.n_nodes;
+    for (uint32_t i = threadIdx.x; i < entries * n_nodes; i += 64u) {
+        const uint32_t e = i / n_nodes, k = i - e * n_nodes;
+        const DevNode& n = a.scene.nodes[k];
+        int4 r = make_int4(0, 0, a.frame.width, a.frame.height);
+        if (n.obj_type != RTU_OBJ_NONE && a.scene.node_bounds) {
+            const float* cp = a.frame_batch ? a.cam[e].pos : a.frame.cam_pos;
+            const float* co = a.frame_batch ? a.cam[e].origin : a.frame.origin;
+            const float* cu = a.frame_batch ? a.cam[e].u : a.frame.u;
+            const float* cv = a.frame_batch ? a.cam[e].v : a.frame.v;
+            const double P[3] = {cp[0], cp[1], cp[2]};
+            const double U[3] = {cu[0], cu[1], cu[2]}, V[3] = {cv[0], cv[1], cv[2]};
+            const double O[3] = {co[0] - P[0], co[1] - P[1], co[2] - P[2]};  // image-plane origin seen from the camera
+            // w = c * (O + a U + b V): Cramer's rule on [U V O]
+            const double det = U[0] * (V[1] * O[2] - V[2] * O[1]) - V[0] * (U[1] * O[2] - U[2] * O[1]) + O[0] * (U[1] * V[2] - U[2] * V[1]);
+            const double pm = fmax(fabs(P[0]), fmax(fabs(P[1]), fabs(P[2])));
+            const double delta = 1e-4 * fmax((double)a.scene.wscale, pm);
+            double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+            bool all_front = det != 0.0;
+            for (int c = 0; c < 8 && all_front; c++) {
+                const double w[3] = {((c & 1) ? (double)n.wmax[0] + delta : (double)n.wmin[0] - delta) - P[0],
+                                     ((c & 2) ? (double)n.wmax[1] + delta : (double)n.wmin[1] - delta) - P[1],
+                                     ((c & 4) ? (double)n.wmax[2] + delta : (double)n.wmin[2] - delta) - P[2]};
+                const double da = w[0] * (V[1] * O[2] - V[2] * O[1]) - V[0] * (w[1] * O[2] - w[2] * O[1]) + O[0] * (w[1] * V[2] - w[2] * V[1]);
+                const double db = U[0] * (w[1] * O[2] - w[2] * O[1]) - w[0] * (U[1] * O[2] - U[2] * O[1]) + O[0] * (U[1] * w[2] - U[2] * w[1]);
+                const double dc = U[0] * (V[1] * w[2] - V[2] * w[1]) - V[0] * (U[1] * w[2] - U[2] * w[1]) + w[0] * (U[1] * V[2] - U[2] * V[1]);
+                const double cc = dc / det;  // depth along the view axis in units of the image-plane distance
+                if (!(cc > 1e-3)) { all_front = false; break; }
+                const double pa = da / dc, pb = db / dc;
+                amin = fmin(amin, pa); amax = fmax(amax, pa);
+                bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+            }
+            if (all_front && amin <= amax && bmin <= bmax) {
+                // pixel x lies on the ray through a = x + 0.5
+                const double W = a.frame.width, H = a.frame.height;
+                const double x0 = floor(fmin(fmax(amin - 2.5, -1.0), W + 1.0)), x1 = ceil(fmin(fmax(amax + 1.5, -1.0), W + 1.0));
+                const double y0 = floor(fmin(fmax(bmin - 2.5, -1.0), H + 1.0)), y1 = ceil(fmin(fmax(bmax + 1.5, -1.0), H + 1.0));
+                r = make_int4((int)fmax(x0, 0.0), (int)fmax(y0, 0.0), (int)fmin(x1, W), (int)fmin(y1, H));
+            }
+        }
+        a.node_rects[i] = r;
+    }
+}
+
 // One kernel of the sequence; `slot` is its timeline / counter-table slot. With a probe on that slot the launch is
 // bracketed by HIP events on the launch stream (bench.py: the dominant kernel's duration inside the timed region).
 #define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
@@ -1203,6 +1264,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     } else if (stats) {
         if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
+        if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridP, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);

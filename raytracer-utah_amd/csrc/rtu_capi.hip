@@ -5,6 +5,9 @@
 // reference's CPU code.
 #include "rtu_device.h"
 
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +66,7 @@ struct RtuContext {
     hipEvent_t probe_ev[2 * kProbePairs] = {};
     struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
     std::vector<MeshInfo> mesh_info;
+    int4* node_rects = nullptr;              // [RTU_MAX_FRAME_BATCH][n_nodes] screen rectangles of the node-level bounds (k_node_rects); owned by the scene
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
     bool stamp_next = false;
 };
@@ -414,6 +418,74 @@ void build_tri_records(const RtuMesh& m, const uint32_t* elements, uint32_t n, s
     }
 }
 
+// NODE-LEVEL BOUNDS (DevNode::wmin / wmax; the argument is in rtu_intersect.h, trace): the object's own bounding box —
+// the unit cube of a sphere, the unit square of a plane (objects.h:25,37), the mesh's box — taken corner by corner through
+// the node's chain of transformations (p -> tm p + pos, scene.h:508-512) in binary64, then widened by
+//   * 1e-5 of the largest coordinate (the chain itself is binary32 on the device and in the reference), and
+//   * for a sphere, what the cancellation in b*b - 4ac can move a grazing root (objFunctions.cpp:25-27): the discriminant
+//     carries an error of ~4 ulp of b*b, i.e. the ray may "touch" a sphere it passes at up to ~2.4e-7 * (D/R)^2 radii, and a
+//     grazing root is off by up to ~5e-4 * D in t; with D bounded by the scene's diameter S both stay below
+//     4e-6 * S^2 / R + 1e-3 * S ... the latter only matters when R < 1e-3 * S, where the former is already larger. R is the
+//     smallest half-extent of the sphere's world box.
+// Returns the largest |coordinate| of all bounds (the scale of the per-ray margin).
+float world_bounds(const RtuSceneDesc* s, std::vector<DevNode>& nodes) {
+    const uint32_t n = s->n_nodes;
+    std::vector<std::array<double, 6>> box(n);
+    std::vector<bool> has(n, false);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < n; i++) {
+        const RtuNode& nd = s->nodes[i];
+        double l[3], h[3];
+        if (nd.obj_type == RTU_OBJ_SPHERE) { l[0] = l[1] = l[2] = -1; h[0] = h[1] = h[2] = 1; }
+        else if (nd.obj_type == RTU_OBJ_PLANE) { l[0] = l[1] = -1; h[0] = h[1] = 1; l[2] = h[2] = 0; }
+        else if (nd.obj_type == RTU_OBJ_TRIMESH) {
+            const RtuMesh& m = s->meshes[nd.mesh_id];
+            for (int k = 0; k < 3; k++) { l[k] = m.bound_min[k]; h[k] = m.bound_max[k]; }
+        } else continue;
+        double wl[3] = {1e300, 1e300, 1e300}, wh[3] = {-1e300, -1e300, -1e300};
+        for (int c = 0; c < 8; c++) {
+            double p[3] = {(c & 1) ? h[0] : l[0], (c & 2) ? h[1] : l[1], (c & 4) ? h[2] : l[2]};
+            for (int j = (int)i; j >= 0; j = s->nodes[j].parent) {
+                const RtuNode& a = s->nodes[j];
+                const double q[3] = {p[0] * a.tm[0] + p[1] * a.tm[3] + p[2] * a.tm[6] + a.pos[0],
+                                     p[0] * a.tm[1] + p[1] * a.tm[4] + p[2] * a.tm[7] + a.pos[1],
+                                     p[0] * a.tm[2] + p[1] * a.tm[5] + p[2] * a.tm[8] + a.pos[2]};
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            }
+            for (int k = 0; k < 3; k++) { wl[k] = std::min(wl[k], p[k]); wh[k] = std::max(wh[k], p[k]); }
+        }
+        for (int k = 0; k < 3; k++) { box[i][k] = wl[k]; box[i][3 + k] = wh[k]; lo[k] = std::min(lo[k], wl[k]); hi[k] = std::max(hi[k], wh[k]); }
+        has[i] = true;
+    }
+    double S = 0;
+    for (int k = 0; k < 3; k++) if (hi[k] >= lo[k]) S += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+    S = std::sqrt(S);
+    double scale = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        DevNode& d = nodes[i];
+        for (int k = 0; k < 3; k++) { d.wmin[k] = -INFINITY; d.wmax[k] = INFINITY; }
+        if (!has[i]) continue;
+        double m = 0;
+        for (int k = 0; k < 6; k++) m = std::max(m, std::fabs(box[i][k]));
+        double widen = 1e-5 * m;
+        if (s->nodes[i].obj_type == RTU_OBJ_SPHERE) {
+            double R = 1e300;
+            for (int k = 0; k < 3; k++) R = std::min(R, 0.5 * (box[i][3 + k] - box[i][k]));
+            widen += R > 0 ? 4e-6 * S * S / R : INFINITY;
+            if (R < 1e-3 * S) widen += 1e-3 * S;
+        }
+        bool finite = std::isfinite(widen);
+        for (int k = 0; k < 3 && finite; k++) finite = std::isfinite(box[i][k]) && std::isfinite(box[i][3 + k]);
+        if (!finite) continue;  // NaN / infinite transformation: no bound (everything passes an infinite box)
+        for (int k = 0; k < 3; k++) {
+            d.wmin[k] = std::nextafter((float)(box[i][k] - widen), -INFINITY);
+            d.wmax[k] = std::nextafter((float)(box[i][3 + k] + widen), INFINITY);
+            scale = std::max(scale, std::max(std::fabs((double)d.wmin[k]), std::fabs((double)d.wmax[k])));
+        }
+    }
+    return (float)scale;
+}
+
 // Reject anything the kernel's indexing does not expect, so that a malformed
 // scene is an error code and never an out-of-bounds access on the GPU.
 int validate(RtuContext* ctx, const RtuSceneDesc* s) {
@@ -652,6 +724,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.defer_list = ctx->defer_list;
     a.defer_cap_s = ctx->defer_cap_s;
     a.counters = stats ? ctx->counters : nullptr;
+    a.node_rects = (stats != 1 && frame->samples == 0 && ctx->dscene.node_bounds) ? ctx->node_rects : nullptr;
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
@@ -948,6 +1021,8 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         }
     }
 
+    const float wscale = world_bounds(s, nodes);
+
     // meshes
     std::vector<RtuContext::MeshInfo> mesh_info;
     std::vector<DevMesh> meshes(s->n_meshes);
@@ -1074,6 +1149,14 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ctx->textured = ds.textured != 0;
     ds.n_nodes = s->n_nodes;
     ds.walk_stack_limit = 0xFFFFu;
+    ds.wscale = wscale;
+    ds.node_bounds = 1;
+    {   // screen rectangles of the node-level bounds, one set per frame in flight (written by k_node_rects on every launch)
+        void* d = nullptr;
+        RTU_HIP(ctx, hipMalloc(&d, sizeof(int4) * (size_t)RTU_MAX_FRAME_BATCH * s->n_nodes));
+        ctx->scene_allocs.push_back(d);
+        ctx->node_rects = static_cast<int4*>(d);
+    }
     ds.n_lights = s->n_lights;
     env_value(s->background, ds.background);
     env_value(s->environment, ds.environment);
@@ -1228,7 +1311,7 @@ int rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots) {
 
 unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured) {
     if (!t) return 0;
-    return 48ull * t->node_tests + 24ull * t->mesh_box_tests + 84ull * t->xform_levels + 112ull * t->inner4 + 256ull * t->inner8 +
+    return 24ull * t->bound_tests + 48ull * t->node_tests + 24ull * t->mesh_box_tests + 84ull * t->xform_levels + 112ull * t->inner4 + 256ull * t->inner8 +
            64ull * t->inner_ref + 64ull * t->tri_tests + (textured ? 148ull : 100ull) * t->winners + t->record_bytes;
 }
 
@@ -1415,6 +1498,12 @@ int rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_u
 int rtu_debug_tail_from(RtuContext* ctx, int level) {
     if (!ctx || level < 1 || level > RTU_MAX_LEVELS) return RTU_ERR_ARG;
     ctx->tail_hint = level;
+    return RTU_OK;
+}
+
+int rtu_debug_node_bounds(RtuContext* ctx, int on) {
+    if (!ctx) return RTU_ERR_ARG;
+    ctx->dscene.node_bounds = on ? 1u : 0u;
     return RTU_OK;
 }
 

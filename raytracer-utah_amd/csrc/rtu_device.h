@@ -69,6 +69,12 @@ struct DevNode {                // one scene-graph node (wave-uniform data)
     float   tm[9], itm[9], pos[3];
     int32_t parent, obj_type, mesh_id, material_id, depth;
     int32_t chain[RTU_MAX_NODE_DEPTH];  // chain[d] = ancestor at depth d (chain[depth] == self)
+    // NODE-LEVEL BOUND (fast variant only; SURVEY row f4 — the reference has Node::ComputeChildBoundBox, scene.h:475-489, and
+    // never uses it): the world-space box of the object's own bounding box (unit cube / unit square / mesh box) taken
+    // through the node's chain of transformations, a little inflated (rtu_capi.hip: world_bounds). A ray that misses it by
+    // the margin of rtu_intersect.h "Culling" cannot pass the reference's own box test of this object, so the node is
+    // skipped before its transformation and exact test — which still decide every result bit of the rays that remain.
+    float   wmin[3], wmax[3];
 };
 
 struct DevTexture {              // RtuTexture with the image in device memory
@@ -91,6 +97,8 @@ struct DevScene {
     uint32_t textured, pad_tex;
     uint32_t n_nodes, n_lights;
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
+    float    wscale;            // largest |coordinate| of any node-level bound: the scale of the cull margin in world space
+    uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
     float    environment[3];    // environment.SampleEnvironment(...) likewise
 };
@@ -160,7 +168,7 @@ struct LevelBuffers {
 
 #define RTU_SHARDS 64
 #define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_impl.h)
-#define RTU_TOUCH_FIELDS 10  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
+#define RTU_TOUCH_FIELDS 11  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
 #define RTU_TOUCH_STRIDE 16  // u64 per timeline slot in the counter table of the touched-bytes mode
 #define RTU_TL_ENDS 8192u   // exit-stamp slots per kernel (wavefront index modulo; a later wavefront overwrites an earlier one)
 #define RTU_TL_STRIDE (64u + RTU_TL_ENDS)
@@ -189,6 +197,8 @@ struct KernelArgs {
     uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
     uint32_t     defer_cap_s;
     uint32_t     pad0;
+    int4*        node_rects;        // recipe W: [batch entry][node] {x0, y0, x1, y1}: the pixels (global x, y; x0 <= x < x1) whose primary ray can
+                                    // touch the node's bound from that entry's camera (k_node_rects); nullptr: not in use
     unsigned long long* counters;   // 11 x u64 (RtuStats order); touched-bytes mode: [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]; or nullptr
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights

@@ -39,7 +39,7 @@ struct Counters {
     unsigned prim, prim_hit, sec, shd, node, mesh, inner, leafv, leafe, tri, acc;
     // touched-bytes mode of the FAST variant (collect_stats == 2, RtuTouched in rtu_render.h): what the timed
     // kernels themselves read and write — their own trees, their own culling, their own two stages
-    unsigned t_rays, t_node, t_meshbox, t_inner4, t_inner8, t_innerref, t_tri, t_win, t_xform, t_bytes;
+    unsigned t_rays, t_node, t_meshbox, t_inner4, t_inner8, t_innerref, t_tri, t_win, t_xform, t_bytes, t_bounds;
 };
 
 #define RTU_CNT(field) do { if (STATS) cnt.field++; } while (0)
@@ -568,6 +568,25 @@ __device__ __forceinline__ bool fast_box(const FastRay& f, float4 lo, float4 hi,
     return tn <= tf && tn <= hz && tf >= 0.0f;
 }
 
+// fast_ray for the node-level bounds: the reciprocals need not be correctly rounded (v_rcp_f32 is within 1 ulp, five
+// orders of magnitude inside the margin), and the scale of the margin is the scene's.
+__device__ __forceinline__ FastRay fast_ray_world(const Ray& ray, float sceneScale) {
+    const float tiny = 0x1p-100f;
+    const float pm = fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z)));
+    const float delta = 1e-4f * (sceneScale > pm ? sceneScale : pm);
+    const float dx = fabsf(ray.dir.x) < tiny ? copysignf(tiny, ray.dir.x) : ray.dir.x;
+    const float dy = fabsf(ray.dir.y) < tiny ? copysignf(tiny, ray.dir.y) : ray.dir.y;
+    const float dz = fabsf(ray.dir.z) < tiny ? copysignf(tiny, ray.dir.z) : ray.dir.z;
+    FastRay f;
+    f.r = mk3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+    const f3 pr = mk3(ray.p.x * f.r.x, ray.p.y * f.r.y, ray.p.z * f.r.z);
+    const f3 L = mk3(delta * fabsf(f.r.x), delta * fabsf(f.r.y), delta * fabsf(f.r.z));
+    f.cn = mk3(-pr.x - L.x, -pr.y - L.y, -pr.z - L.z);
+    f.cf = mk3(-pr.x + L.x, -pr.y + L.y, -pr.z + L.z);
+    f.px = f.r.x >= 0; f.py = f.r.y >= 0; f.pz = f.r.z >= 0;
+    return f;
+}
+
 // The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
 // the order only affects speed: an exact tie between two accepted triangles, the one case where
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
@@ -859,11 +878,26 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 // the bounding box of a mesh node the walk is abandoned and `deferred` is set; the caller
 // queues the ray for the narrow-wavefront stage-2 kernel, which walks the whole scene
 // again with DEFER=false. Rays that never touch a mesh complete in stage 1.
+//
+// NODE-LEVEL BOUNDS (CULL only, i.e. the fast variant; DevNode::wmin / wmax). Every hit the reference can report lies, within
+// rounding, inside the object's own bounding box: Box::IntersectRay on that box is the first thing Sphere / Plane /
+// TriObj::IntersectRay do (objFunctions.cpp:17, :109, :335), its slab arithmetic is good to a few ulp of the ray's
+// coordinates, and where its exactly-zero-direction branches ignore an axis (:154-216) the accepted hit point itself is on
+// the sphere, inside the square or inside a triangle. So a ray whose line, between its origin and the best hit so far, stays
+// clear of the box by delta = 1e-4 * max(scene scale, |origin|) on some axis — the geometric form of "Culling" above, on
+// the world-space box of the node — cannot produce a result there, and the node is skipped before its transformation
+// and exact test. (The margin is 100 x the slab rounding; the bound of a sphere is widened further at upload by what the
+// cancellation in its discriminant can move a grazing root, rtu_capi.hip world_bounds.) `skip` marks nodes the caller
+// has already excluded in the same sense: for primary rays, pixels outside the node's screen rectangle (k_node_rects).
 template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
-                                      const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
+                                      const uint32_t stride = 64, const float4* lds_nodes = nullptr, const unsigned long long skip = 0,
+                                      const bool rays_bounded = false) {
     const bool fc_lane = !COOP || (threadIdx.x & 7u) == 0;
     RTU_TOUCH(t_rays, 1);
+    const bool bounds = CULL && s.node_bounds != 0 && !rays_bounded;  // wave-uniform
+    FastRay wf = {};
+    if (bounds) wf = fast_ray_world(wr, s.wscale);
     const RTU_CONST DevNode* nodes = as_const(s.nodes);
     const RTU_CONST DevMesh* meshes = as_const(s.meshes);
     bool any = false;
@@ -878,6 +912,12 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         if (n.obj_type == RTU_OBJ_NONE) continue;
         if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
         if (DEFER && deferred) continue;
+        if (CULL && k < 64u && ((skip >> k) & 1ull)) continue;
+        if (bounds) {
+            float tn;
+            RTU_TOUCH(t_bounds, 1);
+            if (!fast_box(wf, make_float4(n.wmin[0], n.wmin[1], n.wmin[2], 0.0f), make_float4(n.wmax[0], n.wmax[1], n.wmax[2], 0.0f), h.z, tn)) continue;
+        }
         int parent = n.parent;
         Ray pr;
         if (parent < 0) {

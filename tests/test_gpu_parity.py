@@ -687,3 +687,90 @@ def test_touched_bytes_mode_is_the_fast_variant_counting_itself(pkg, ctx, golden
         _, ref = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
         inner = sum(c["inner4"] + c["inner8"] + c["inner_ref"] for c in t.values())
         assert 0 < inner < ref["inner_visits"]
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p4_240x135", "p11_240x135", "p13_200x150", "p7_200x150", "p5_200x150"])
+def test_node_level_bounds_change_nothing_but_the_work(pkg, ctx, golden, tag):
+    """a world-space box per scene node (and its screen rectangle per camera for primary rays) lets a ray skip the
+    nodes it cannot touch before their transformation and exact test. Same image bit for bit with the bounds on and off
+    (rtu_debug_node_bounds), single frame and frames in flight with turned cameras, both stage-2 forms — and fewer exact
+    node tests with them on."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    cams = []
+    for i in range(3):
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        cam.pos[0] += 1.3 * i
+        cam.pos[2] -= 0.7 * i
+        cam.fov += 9.0 * i
+        cams.append(cam)
+    d = pkg.hip.rtu_device_alloc(ctx._h, 3 * W * H * 16)
+    res = {}
+    for on in (1, 0):
+        assert pkg.hip.rtu_debug_node_bounds(ctx._h, on) == 0
+        imgs = []
+        for coop in (1, 10 ** 9):
+            fr = pkg.frame_setup(cams[0], W, H)
+            fr.coop_threshold = coop
+            imgs.append(ctx.render(fr)[0])
+            frames = [pkg.frame_setup(c, W, H, collect_stats=2) for c in cams]
+            for f in frames:
+                f.coop_threshold = coop
+            ctx.render_frames_device(frames, d, None)
+            ctx.frame_status()
+            out = np.empty((3, H, W, 4), np.float32)
+            assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+            imgs.append(out)
+        t = ctx.touched(scene.desc.n_textures > 0)
+        res[on] = (imgs, sum(c["node_tests"] for c in t.values()), sum(c["bound_tests"] for c in t.values()))
+    pkg.hip.rtu_debug_node_bounds(ctx._h, 1)
+    pkg.hip.rtu_device_free(ctx._h, d)
+    for a, b in zip(res[1][0], res[0][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "node-level bounds changed the image"
+    assert res[0][2] == 0 and res[1][2] > 0
+    assert res[1][1] < res[0][1], "the bounds skipped nothing: %d vs %d exact node tests" % (res[1][1], res[0][1])
+    cpu, _ = __import__("__graft_entry__").load_oracle().render(scene, W, H, threads=8)
+    check_against(res[1][0][0], cpu, __import__("__graft_entry__").load_oracle())
+
+
+def test_node_level_bounds_on_adversarial_rays(pkg, orc, tmp_path):
+    """Where the bound's argument is thinnest: a tiny sphere far from everything (its discriminant is cancellation noise:
+    the bound is widened at upload), axis-parallel rays (the reference's box test ignores an axis when a direction component is
+    exactly zero: odd resolution, camera on an axis, so the centre column and row have such rays), a squashed sphere as a wall,
+    nested transformations. Fast variant == counting variant == oracle."""
+    xml = tmp_path / "adv.xml"
+    xml.write_text("""<xml><scene>
+      <object type="sphere" name="wall" material="wall"><scale x="40" y="40" z="0.5"/><translate z="-3"/></object>
+      <object type="sphere" name="speck" material="mirror"><scale value="0.02"/><translate x="0" y="30" z="0"/></object>
+      <object name="group"><rotate angle="33" z="1"/><translate x="-2" y="4" z="0"/>
+        <object type="sphere" name="ball" material="glass"><scale value="1.5"/><translate x="1" y="0" z="0.5"/>
+          <object type="plane" name="card" material="wall"><scale value="0.8"/><rotate angle="90" x="1"/><translate x="0" y="-2" z="0"/></object>
+        </object>
+      </object>
+      <object type="plane" name="floor" material="floor"><scale value="25"/><translate z="-2.5"/></object>
+      <material type="blinn" name="wall"><diffuse r="0.7" g="0.6" b="0.5"/><specular value="0.2"/><glossiness value="10"/></material>
+      <material type="blinn" name="floor"><diffuse r="0.4" g="0.5" b="0.4"/><specular value="0.1"/><reflection value="0.3"/></material>
+      <material type="blinn" name="mirror"><diffuse value="0.1"/><specular value="0.9"/><glossiness value="90"/><reflection value="0.9"/></material>
+      <material type="blinn" name="glass"><diffuse value="0.05"/><specular value="0.8"/><glossiness value="60"/><refraction index="1.45" value="0.9"/></material>
+      <light type="ambient" name="a"><intensity value="0.2"/></light>
+      <light type="point" name="p"><intensity value="0.7"/><position x="0" y="-5" z="20"/></light>
+      <light type="direct" name="d"><intensity value="0.4"/><direction x="0" y="1" z="-1"/></light>
+    </scene><camera><position x="0" y="-20" z="0"/><target x="0" y="0" z="0"/><up x="0" y="0" z="1"/><fov value="50"/>
+      <width value="161"/><height value="101"/></camera></xml>""")
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 161, 101
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(scene)
+        cpu, cst = orc.render(scene, W, H, threads=8)
+        cnt, gst = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+        assert gst == cst
+        for on in (1, 0):
+            pkg.hip.rtu_debug_node_bounds(ctx._h, on)
+            fast, _ = ctx.render(pkg.frame_setup(scene.desc.camera, W, H))
+            assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast (bounds %d) and counting variants differ" % on
+        check_against(fast, cpu, orc)
+    finally:
+        ctx.close()

@@ -93,6 +93,7 @@ def main():
                     help="N>1: gather the float4 {r,g,b,z} shards (16 B per pixel) instead of the packed RenderImage content "
                          "(float z + Color24, 7 B per pixel, converted on the device)")
     ap.add_argument("--allgather", action="store_true", help="N>1: all_gather the framebuffer to every rank instead of gathering it to rank 0")
+    ap.add_argument("--dbg", type=int, default=0, help="experiment switches (rtu_debug_flags): the images are WRONG with anything but 0")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 on a box with ONE GPU: every rank renders its shard on cuda:0 and the gather goes through gloo on host "
                          "copies. Exercises the sharded code path; the number it prints is not a measurement")
@@ -136,6 +137,8 @@ def main():
         meta = dict(meta, sha256_z_f32=None)
     ctx = pkg.Context(local_rank)
     ctx.upload(scene)  # inputs resident in HBM before any timing
+    if args.dbg:
+        pkg.hip.rtu_debug_flags(ctx._h, args.dbg)
     textured = scene.desc.n_textures > 0
     sampled = args.samples > 0
 

@@ -197,6 +197,10 @@ int  rtu_debug_tail_from(RtuContext* ctx, int level);
  * nodes it cannot touch before their transformation and exact test. Results must not change. */
 int  rtu_debug_node_bounds(RtuContext* ctx, int on);
 
+/* Experiment switches for performance work (which part of a kernel costs what): bits are defined next to their use in
+ * render_impl.h; anything but 0 renders WRONG images. Never set in production paths or tests of results. */
+int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
+
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
  * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would
  * need more is finished on the reference's tree — on any scene. Results must not change. */

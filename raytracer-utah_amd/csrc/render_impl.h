@@ -56,6 +56,19 @@ namespace {
 // same images — counting per kernel launch what they read and write (Counters::t_*, RtuTouched in rtu_render.h). The
 // roofline of bench.py is computed from these counters, i.e. from the work the timed kernels themselves do.
 #define CNTD ((TEX & 16) != 0)
+// occupancy hints per kernel family (amdgpu_waves_per_eu), see DESIGN.md 5 for what was measured
+#ifndef RTU_OCC_PRIMARY
+#define RTU_OCC_PRIMARY
+#endif
+#ifndef RTU_OCC_TRACE
+#define RTU_OCC_TRACE
+#endif
+#ifndef RTU_OCC_WALK
+#define RTU_OCC_WALK
+#endif
+#ifndef RTU_OCC_CONSUME
+#define RTU_OCC_CONSUME
+#endif
 #define RTU_BYTES(n) do { if (CNTD) cnt.t_bytes += (n); } while (0)
 
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
@@ -100,7 +113,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // Largest shard population of level L (wave-uniform): lane i reads shard i's counter.
 __device__ __forceinline__ uint32_t level_max_count(const KernelArgs& a, int L) {
-    uint32_t v = a.fcnt->n_frames[L][lane_id() % RTU_SHARDS];
+    uint32_t v = a.fcnt->n_frames[L][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
     const uint32_t cap = a.lv[L].cap_s;
     if (v > cap) v = cap;
 #pragma unroll
@@ -111,7 +124,7 @@ __device__ __forceinline__ uint32_t level_max_count(const KernelArgs& a, int L) 
     return v;
 }
 __device__ __forceinline__ uint32_t shard_count(const KernelArgs& a, int L, uint32_t shard) {
-    uint32_t v = a.fcnt->n_frames[L][shard];
+    uint32_t v = a.fcnt->n_frames[L][(shard) * RTU_CSTRIDE];
     const uint32_t cap = a.lv[L].cap_s;
     return v > cap ? cap : v;
 }
@@ -185,9 +198,9 @@ __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, 
     if (mf) {
         const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
         if ((threadIdx.x & 63u) == leader) {
-            bf = atomicAdd(&a.fcnt->n_frames[0][shard], (uint32_t)__popcll(mf));
-            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][shard], (uint32_t)__popcll(mm));
-            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][shard], (uint32_t)__popcll(mc));
+            bf = atomicAdd(&a.fcnt->n_frames[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mf));
+            if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mm));
+            if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mc));
         }
         bf = (uint32_t)__shfl((int)bf, (int)leader);
         bm = (uint32_t)__shfl((int)bm, (int)leader);
@@ -264,7 +277,7 @@ __device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) 
 
 // Append one ray id to the defer list of phase `ph` (sharded like the frame arrays).
 __device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t shard, bool want, uint32_t id) {
-    uint32_t idx = wave_append(&a.fcnt->n_defer[ph][shard], want);
+    uint32_t idx = wave_append(&a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE], want);
     if (want) {
         if (idx < a.defer_cap_s) a.defer_list[(size_t)shard * a.defer_cap_s + idx] = id;
         else a.fcnt->overflow = 1;
@@ -276,7 +289,7 @@ struct NarrowGeom {
     uint32_t R, kmax, nmax, sum;
 };
 __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
-    uint32_t v = a.fcnt->n_defer[ph][lane_id() % RTU_SHARDS];
+    uint32_t v = a.fcnt->n_defer[ph][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
     if (v > a.defer_cap_s) v = a.defer_cap_s;
     uint32_t sum = v;
 #pragma unroll
@@ -378,11 +391,12 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             }
             if (CNTD && leader) cnt.t_bytes += 16u * nn;
         }
-        bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes, skip, rects);
+        bool hit = false;
+        if (!(a.dbg & 4u)) hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes, skip, rects);
         if (!deferred && leader) {
             if (!hit) {
                 f3 bg = background_sample<TEXD>(s, x, y);  // :145
-                a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
+                if (!(a.dbg & 16u)) a.out[pix] = make_float4(bg.x, bg.y, bg.z, h.z);
                 RTU_BYTES(16u);
             } else {
                 RTU_CNT(prim_hit);
@@ -402,12 +416,12 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     if (GID) return;
     uint32_t info = 0;
     if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
-    append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
+    if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
 template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles) {
+__global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, uint32_t n_tiles) {
     const Stamp stamp(a, RTU_TL_PRIMARY);
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
     uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
@@ -427,7 +441,7 @@ __global__ void __launch_bounds__(256) k_primary(KernelArgs a, uint32_t n_tiles)
     Counters cnt = {};
     bool deferred;
     primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
-    if (!STATS) defer_push(a, 0, shard, deferred, pix);
+    if (!STATS && !(a.dbg & 8u)) defer_push(a, 0, shard, deferred, pix);
     if (deferred) RTU_BYTES(4u);
     flush_counters<STATS>(a, cnt);
     flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY);
@@ -446,7 +460,7 @@ __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nod
 
 // stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
+__global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
     const Stamp stamp(a, RTU_TL_PRIMARY2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
@@ -457,7 +471,7 @@ __global__ void __launch_bounds__(64) k_primary2(KernelArgs a) {
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][shard];
+        uint32_t ns = a.fcnt->n_defer[0][(shard) * RTU_CSTRIDE];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
         const uint32_t e = k * 64u + lane;
         const bool valid = e < ns;
@@ -495,7 +509,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][shard];
+        uint32_t ns = a.fcnt->n_defer[0][(shard) * RTU_CSTRIDE];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
         const uint32_t e = k * groups + grp;
         const bool valid = e < ns;
@@ -594,13 +608,13 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
 
 // stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
 template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int ph) {
+__global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
     // shadow slots: every frame of the level; secondary slots: the frames listed for them (list_frame)
-    uint32_t vm = a.fcnt->n_lmain[L][lane % RTU_SHARDS], vc = a.fcnt->n_lrefl[L][lane % RTU_SHARDS];
+    uint32_t vm = a.fcnt->n_lmain[L][(lane % RTU_SHARDS) * RTU_CSTRIDE], vc = a.fcnt->n_lrefl[L][(lane % RTU_SHARDS) * RTU_CSTRIDE];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         uint32_t o = (uint32_t)__shfl_xor((int)vm, off);
@@ -633,15 +647,15 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
         }
         const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
         const uint32_t e = k * 64u + lane;
-        uint32_t ns = counts[shard];
+        uint32_t ns = counts[shard * RTU_CSTRIDE];
         if (ns > lv.cap_s) ns = lv.cap_s;
         const bool active = e < ns;
         const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
         if (active && list) RTU_BYTES(4u);
         const uint32_t f = shard * lv.cap_s + fl;
         bool deferred = false;
-        if (active) deferred = frame_ray<STACK, STATS, !STATS, false, TEX>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
-        if (!STATS) defer_push(a, ph, shard, deferred, (slot << 28) | f);
+        if (active && !(a.dbg & 2u)) deferred = frame_ray<STACK, STATS, !STATS, false, TEX>(a, L, sel, slot, f, s_stack + (STATS ? lane : 0), cnt);
+        if (!STATS && !(a.dbg & 1u)) defer_push(a, ph, shard, deferred, (slot << 28) | f);
         if (deferred) RTU_BYTES(4u);
     }
     flush_counters<STATS>(a, cnt);
@@ -650,7 +664,7 @@ __global__ void __launch_bounds__(64) k_trace(KernelArgs a, int L, int sel, int 
 
 // stage 2, long lists: one lane per deferred ray
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int ph) {
+__global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
@@ -661,7 +675,7 @@ __global__ void __launch_bounds__(64) k_trace2(KernelArgs a, int L, int sel, int
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][shard];
+        uint32_t ns = a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
         const uint32_t e = k * 64u + lane;
         if (e >= ns) continue;
@@ -691,7 +705,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][shard];
+        uint32_t ns = a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE];
         if (ns > a.defer_cap_s) ns = a.defer_cap_s;
         const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
@@ -860,7 +874,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
         uint32_t base = 0;
         if (n0 + n1 + n2) {
-            if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][cshard], n0 + n1 + n2);
+            if (lane == 0) base = atomicAdd(&a.fcnt->n_frames[Ln][(cshard) * RTU_CSTRIDE], n0 + n1 + n2);
             base = (uint32_t)__shfl((int)base, 0);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -914,9 +928,9 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         const uint32_t na = (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2)), nc = (uint32_t)(__popcll(c0) + __popcll(c1) + __popcll(c2));
         uint32_t ba = 0, bc = 0, bp = 0;
         if (lane == 0) {  // independent atomics: issued back to back, one wait
-            if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][cshard], na);
-            if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][cshard], nc);
-            if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][shard], (uint32_t)__popcll(pm));
+            if (na) ba = atomicAdd(&a.fcnt->n_lmain[Ln][(cshard) * RTU_CSTRIDE], na);
+            if (nc) bc = atomicAdd(&a.fcnt->n_lrefl[Ln][(cshard) * RTU_CSTRIDE], nc);
+            if (pm) bp = atomicAdd(&a.fcnt->n_pending[L][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(pm));
         }
         ba = (uint32_t)__shfl((int)ba, 0);
         bc = (uint32_t)__shfl((int)bc, 0);
@@ -949,7 +963,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
 }
 
 template <bool STATS, int TEX>
-__global__ void __launch_bounds__(64) k_consume(KernelArgs a, int L) {
+__global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
@@ -1017,7 +1031,7 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_COMBINE0 + L);
     const LevelBuffers& lv = a.lv[L];
     // only the frames k_consume listed as waiting for children
-    uint32_t pmax = a.fcnt->n_pending[L][lane_id() % RTU_SHARDS];
+    uint32_t pmax = a.fcnt->n_pending[L][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)pmax, off);
@@ -1028,7 +1042,7 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t e = k * 64u + threadIdx.x;
-        if (e >= a.fcnt->n_pending[L][shard]) continue;
+        if (e >= a.fcnt->n_pending[L][(shard) * RTU_CSTRIDE]) continue;
         const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
         RTU_BYTES(4u);
         combine_frame<TEX>(a, L, f, cnt);

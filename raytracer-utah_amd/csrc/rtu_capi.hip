@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,7 @@ struct RtuContext {
     hipEvent_t probe_ev[2 * kProbePairs] = {};
     struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
     std::vector<MeshInfo> mesh_info;
+    uint32_t dbg = 0;
     int4* node_rects = nullptr;              // [RTU_MAX_FRAME_BATCH][n_nodes] screen rectangles of the node-level bounds (k_node_rects); owned by the scene
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
     bool stamp_next = false;
@@ -723,6 +725,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.tl = ctx->stamp_next ? ctx->tl : nullptr;
     a.defer_list = ctx->defer_list;
     a.defer_cap_s = ctx->defer_cap_s;
+    a.dbg = ctx->dbg;
+    a.scene.dbg = ctx->dbg;
     a.counters = stats ? ctx->counters : nullptr;
     a.node_rects = (stats != 1 && frame->samples == 0 && ctx->dscene.node_bounds) ? ctx->node_rects : nullptr;
     a.tiles_x = tiles_x;
@@ -792,7 +796,7 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
     uint32_t frames[RTU_MAX_LEVELS];
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         frames[L] = 0;
-        for (int s = 0; s < RTU_SHARDS; s++) frames[L] += h.n_frames[L][s];
+        for (int s = 0; s < RTU_SHARDS; s++) frames[L] += h.n_frames[L][(s) * RTU_CSTRIDE];
     }
     const int used = ctx->last_tail_from;  // levels > used were not materialised: their counts are unknown (zero)
     const int top = used < RTU_MAX_LEVELS ? used : RTU_MAX_LEVELS - 1;
@@ -807,7 +811,8 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
 // first overflowing level really needs (deeper levels may need another round: their parents were
 // dropped). Wanted capacities grow to the reported counts (+25 %, at least x2 for the level below).
 int check_overflow(RtuContext* ctx, bool* overflow) {
-    FrameCounters h;
+    std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
+    FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     *overflow = h.overflow != 0;
     if (!*overflow) {
@@ -818,7 +823,7 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     bool grew = false;
     for (int L = 1; L < RTU_MAX_LEVELS; L++) {
         uint32_t need = 0;
-        for (int s = 0; s < RTU_SHARDS; s++) need = h.n_frames[L][s] > need ? h.n_frames[L][s] : need;
+        for (int s = 0; s < RTU_SHARDS; s++) need = h.n_frames[L][(s) * RTU_CSTRIDE] > need ? h.n_frames[L][(s) * RTU_CSTRIDE] : need;
         if (need > ctx->lv[L].cap_s) {
             size_t w = ((size_t)need + need / 4 + 63) / 64 * 64;
             if (w > ctx->want_cap_s[L]) ctx->want_cap_s[L] = (uint32_t)w;
@@ -829,7 +834,7 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     }
     uint32_t dneed = 0;
     for (int p = 0; p <= RTU_MAX_LEVELS; p++)
-        for (int s = 0; s < RTU_SHARDS; s++) dneed = h.n_defer[p][s] > dneed ? h.n_defer[p][s] : dneed;
+        for (int s = 0; s < RTU_SHARDS; s++) dneed = h.n_defer[p][(s) * RTU_CSTRIDE] > dneed ? h.n_defer[p][(s) * RTU_CSTRIDE] : dneed;
     if (dneed > ctx->defer_cap_s) {
         ctx->want_defer_s = dneed + dneed / 4;
         grew = true;
@@ -1290,7 +1295,8 @@ int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     RTU_HIP(ctx, hipDeviceSynchronize());
     static_assert(sizeof(RtuStats) == 11 * sizeof(unsigned long long), "RtuStats layout");
     RTU_HIP(ctx, hipMemcpy(stats, ctx->counters, sizeof(RtuStats), hipMemcpyDeviceToHost));
-    FrameCounters h;
+    std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
+    FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     if (!h.overflow) learn_tail(ctx, h);
     return RTU_OK;
@@ -1501,6 +1507,12 @@ int rtu_debug_tail_from(RtuContext* ctx, int level) {
     return RTU_OK;
 }
 
+int rtu_debug_flags(RtuContext* ctx, uint32_t bits) {
+    if (!ctx) return RTU_ERR_ARG;
+    ctx->dbg = bits;
+    return RTU_OK;
+}
+
 int rtu_debug_node_bounds(RtuContext* ctx, int on) {
     if (!ctx) return RTU_ERR_ARG;
     ctx->dscene.node_bounds = on ? 1u : 0u;
@@ -1524,15 +1536,16 @@ int rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_o
     if (!ctx || !frames_out || !deferred_out) return RTU_ERR_ARG;
     RTU_HIP(ctx, hipSetDevice(ctx->device));
     RTU_HIP(ctx, hipDeviceSynchronize());
-    FrameCounters h;
+    std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
+    FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         frames_out[L] = 0;
-        for (int s = 0; s < RTU_SHARDS; s++) frames_out[L] += h.n_frames[L][s];
+        for (int s = 0; s < RTU_SHARDS; s++) frames_out[L] += h.n_frames[L][(s) * RTU_CSTRIDE];
     }
     for (int p = 0; p <= RTU_MAX_LEVELS; p++) {
         deferred_out[p] = 0;
-        for (int s = 0; s < RTU_SHARDS; s++) deferred_out[p] += h.n_defer[p][s];
+        for (int s = 0; s < RTU_SHARDS; s++) deferred_out[p] += h.n_defer[p][(s) * RTU_CSTRIDE];
     }
     return RTU_OK;
 }

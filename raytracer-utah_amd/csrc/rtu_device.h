@@ -98,6 +98,7 @@ struct DevScene {
     uint32_t n_nodes, n_lights;
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    wscale;            // largest |coordinate| of any node-level bound: the scale of the cull margin in world space
+    uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg
     uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
     float    environment[3];    // environment.SampleEnvironment(...) likewise
@@ -173,14 +174,19 @@ struct LevelBuffers {
 #define RTU_TL_ENDS 8192u   // exit-stamp slots per kernel (wavefront index modulo; a later wavefront overwrites an earlier one)
 #define RTU_TL_STRIDE (64u + RTU_TL_ENDS)
 
+// Device-scope atomics execute at the memory side (the eight XCD L2s are not coherent), a round trip of microseconds, and
+// adds to ONE 128-byte line are served one after the other: with the 64 shard counters of a list packed into two lines the
+// appends of k_trace(L0) cost 250 of its 373 us (measured: rtu_debug_flags bit 0). So every counter has a line of its own:
+// counter of shard s = word [s * RTU_CSTRIDE].
+#define RTU_CSTRIDE 32u
 struct FrameCounters {
-    uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS];
-    uint32_t n_defer[RTU_MAX_LEVELS + 1][RTU_SHARDS];  // phase 0 = primary rays, phase 1+L = rays of level L
-    uint32_t n_pending[RTU_MAX_LEVELS][RTU_SHARDS];    // frames waiting for children (fpend)
-    uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS];      // entries of lmain / lrefl
-    uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS];
-    uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more
-    uint32_t pad[3];
+    uint32_t n_frames[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];
+    uint32_t n_defer[RTU_MAX_LEVELS + 1][RTU_SHARDS * RTU_CSTRIDE];  // phase 0 = primary rays, phase 1+L = rays of level L
+    uint32_t n_pending[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];    // frames waiting for children (fpend)
+    uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];      // entries of lmain / lrefl
+    uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];
+    uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more (sticky: rtu_frame_status)
+    uint32_t pad[31];
 };
 
 struct BatchCam {
@@ -196,7 +202,7 @@ struct KernelArgs {
     FrameCounters* fcnt;
     uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
     uint32_t     defer_cap_s;
-    uint32_t     pad0;
+    uint32_t     dbg;               // experiment switches (rtu_debug_flags); 0 in production
     int4*        node_rects;        // recipe W: [batch entry][node] {x0, y0, x1, y1}: the pixels (global x, y; x0 <= x < x1) whose primary ray can
                                     // touch the node's bound from that entry's camera (k_node_rects); nullptr: not in use
     unsigned long long* counters;   // 11 x u64 (RtuStats order); touched-bytes mode: [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]; or nullptr

@@ -948,7 +948,7 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
             hit = box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT) &&  // TriObj::IntersectRay's own box test (:335)
                   mesh_hit_coop<STACK, CULL, FC>(mesh, lr, shadow, h, stk, cnt, stride, lds_nodes, s.walk_stack_limit);
         } else {
-            hit = mesh_hit<STACK, STATS, CULL, FC>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, s.walk_stack_limit);
+            hit = (s.dbg & 32u) ? false : mesh_hit<STACK, STATS, CULL, FC>(meshes[n.mesh_id], lr, shadow, h, stk, cnt, s.walk_stack_limit);
         }
         if (hit) {
             any = true;

@@ -333,6 +333,29 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     Smp smp;
     smp.on = SMPD;
     smp.key = 0;
+    // node-level bounds of a primary ray (recipe W): the pixel against every node's screen rectangle for this camera
+    // (k_node_rects). A wavefront whose pixels lie outside every rectangle has nothing to trace: background, done.
+    unsigned long long skip = 0;
+    const bool rects = !STATS && !SMPD && a.node_rects != nullptr;
+    if (rects) {
+        const RTU_CONST int* rc = as_const(reinterpret_cast<const int*>(a.node_rects)) + 4u * (size_t)sidx * s.n_nodes;  // scalar loads where sidx is wave-uniform
+        const uint32_t nn = s.n_nodes < 64u ? s.n_nodes : 64u;
+        for (uint32_t k = 0; k < nn; k++) {
+            const int x0 = rc[4u * k], y0 = rc[4u * k + 1u], x1 = rc[4u * k + 2u], y1 = rc[4u * k + 3u];
+            if (x < x0 || x >= x1 || y < y0 || y >= y1) skip |= 1ull << k;
+        }
+        if (CNTD && leader && valid) cnt.t_bytes += 16u * nn;
+        if (s.n_nodes <= 64u && __all(!valid || (skip & s.obj_mask) == s.obj_mask)) {
+            if (valid && leader) {
+                RTU_CNT(prim);
+                const f3 bg = background_sample<TEXD>(s, x, y);  // :145
+                a.out[pix] = make_float4(bg.x, bg.y, bg.z, RTU_BIGFLOAT);
+                RTU_BYTES(16u);
+                if (CNTD) cnt.t_rays++;  // the ray exists; it touches nothing
+            }
+            return;
+        }
+    }
     if (GID && a.gi_depth > 0) {
         // recipe P, chain depth k > 0: the gather ray from the hit of depth k - 1 (RenderFunctions.cpp:556-565)
         const size_t hb = (size_t)(a.gi_depth - 1u) * 4u * a.gi_total + pix;
@@ -379,18 +402,6 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         f3 cp = (cam_origin + cam_u * ((float)x + ox)) + cam_v * ((float)y + oy);
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
-        // node-level bounds of a primary ray: the pixel against every node's screen rectangle for this camera (k_node_rects)
-        unsigned long long skip = 0;
-        const bool rects = !STATS && !SMPD && a.node_rects != nullptr;
-        if (rects) {
-            const RTU_CONST int* rc = as_const(reinterpret_cast<const int*>(a.node_rects)) + 4u * (size_t)sidx * s.n_nodes;  // wave-uniform: scalar loads
-            const uint32_t nn = s.n_nodes < 64u ? s.n_nodes : 64u;
-            for (uint32_t k = 0; k < nn; k++) {
-                const int x0 = rc[4u * k], y0 = rc[4u * k + 1u], x1 = rc[4u * k + 2u], y1 = rc[4u * k + 3u];
-                if (x < x0 || x >= x1 || y < y0 || y >= y1) skip |= 1ull << k;
-            }
-            if (CNTD && leader) cnt.t_bytes += 16u * nn;
-        }
         bool hit = false;
         if (!(a.dbg & 4u)) hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes, skip, rects);
         if (!deferred && leader) {
@@ -426,23 +437,24 @@ __global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, u
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
     uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t btile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (btile >= n_tiles) return;  // whole wavefront
-    const uint32_t sidx = (SMPD || BATD) ? btile / a.tiles_per_image : 0u;  // batched launches: n_tiles = batch x tiles of the image
-    const uint32_t tile = btile - sidx * a.tiles_per_image;
-    const uint32_t band_local = tile / a.tiles_x;
-    const uint32_t tx = tile - band_local * a.tiles_x;
-    const int x = (int)(tx * 8 + (lane & 7));
-    const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
-    const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
-    const bool valid = x < a.frame.width && y < a.frame.height;
-    const uint32_t pix = ((SMPD || BATD) ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
-    const uint32_t shard = btile % RTU_SHARDS;
     Counters cnt = {};
-    bool deferred;
-    primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
-    if (!STATS && !(a.dbg & 8u)) defer_push(a, 0, shard, deferred, pix);
-    if (deferred) RTU_BYTES(4u);
+    // tiles are strided over the grid (a wavefront renders several: the launch has fewer, longer-lived wavefronts)
+    for (uint32_t btile = blockIdx.x * 4u + (threadIdx.x >> 6); btile < n_tiles; btile += gridDim.x * 4u) {  // whole wavefronts
+        const uint32_t sidx = (SMPD || BATD) ? btile / a.tiles_per_image : 0u;  // batched launches: n_tiles = batch x tiles of the image
+        const uint32_t tile = btile - sidx * a.tiles_per_image;
+        const uint32_t band_local = tile / a.tiles_x;
+        const uint32_t tx = tile - band_local * a.tiles_x;
+        const int x = (int)(tx * 8 + (lane & 7));
+        const int ly = (int)(band_local * RTU_BAND_ROWS + (lane >> 3));                                              // row inside the shard
+        const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
+        const bool valid = x < a.frame.width && y < a.frame.height;
+        const uint32_t pix = ((SMPD || BATD) ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+        const uint32_t shard = btile % RTU_SHARDS;
+        bool deferred;
+        primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
+        if (!STATS && !(a.dbg & 8u)) defer_push(a, 0, shard, deferred, pix);
+        if (deferred) RTU_BYTES(4u);
+    }
     flush_counters<STATS>(a, cnt);
     flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY);
 }
@@ -1271,7 +1283,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     // instead of 2048 for k_consume balance the chunks better, -8 %; a single frame is unchanged)
     const dim3 gridT(8192), gridN(32768), gridS(8192), gridF(4096), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
-    const dim3 gridP((n_tiles + 3) / 4);
+    // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
+    const uint32_t blocksP = (n_tiles + 3) / 4;
+    const dim3 gridP(blocksP), gridPF(blocksP < 32768u ? blocksP : 32768u);
     if (CNTD) stats = false;  // the touched-bytes instantiations are the fast variant's (the reference-counting kernels are not built for them)
     if (mode == RTU_LAUNCH_SHADE) {
         hipLaunchKernelGGL((k_gi_roots<TEX>), gridN, block, 0, stream, a);
@@ -1279,7 +1293,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
-        RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridP, dim3(256), a, n_tiles);
+        RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);
             RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), gridN, block, a);

@@ -1155,6 +1155,9 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ds.n_nodes = s->n_nodes;
     ds.walk_stack_limit = 0xFFFFu;
     ds.wscale = wscale;
+    ds.obj_mask = 0;
+    for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
+        if (s->nodes[i].obj_type != RTU_OBJ_NONE) ds.obj_mask |= 1ull << i;
     ds.node_bounds = 1;
     {   // screen rectangles of the node-level bounds, one set per frame in flight (written by k_node_rects on every launch)
         void* d = nullptr;

@@ -98,6 +98,7 @@ struct DevScene {
     uint32_t n_nodes, n_lights;
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    wscale;            // largest |coordinate| of any node-level bound: the scale of the cull margin in world space
+    unsigned long long obj_mask;  // bit k: node k (< 64) carries an object
     uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg
     uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background

@@ -159,11 +159,30 @@ __device__ __forceinline__ void flush_touched(const KernelArgs& a, const Counter
 
 // Which rays will this Shade() call fire? Decided once, when the frame is created.
 template <int TEX>
-__device__ __forceinline__ uint32_t make_info(const DevScene& s, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp, bool amb = false) {
+__device__ __forceinline__ uint32_t make_info(const KernelArgs& a, int mtl, int bounce, bool front, f3 dir, f3 p, f3 N, f3 uvw, Smp smp, bool amb = false) {
+    const DevScene& s = a.scene;
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[mtl];
     uint32_t info = (uint32_t)mtl | ((uint32_t)bounce << RTU_FI_BOUNCE_SH) | (front ? RTU_FI_FRONT : 0u);
     if (amb) info |= RTU_FI_AMB;                                         // the light list is one AmbientLight: no shadow rays
     else if (front && s.n_lights > 0) info |= RTU_FI_SH;                 // mtlFunctions.cpp:125
+    // LIGHTS BEHIND THE SURFACE. The light loop clamps N.L at zero (:141-148) and multiplies the light's whole term by it
+    // (:152): with N.L <= 0 the term is Illuminate() * (+-0) * (...) = +-0 whether Shadow() returned 0 or 1 — as long as
+    // Illuminate() is finite either way, which it is for a finite intensity below 1e15 (nol_ok) at more than 1e-10 from a
+    // point light. So no shadow ray is needed there (the fast variant fires none, frame_ray; the counting variant does, and
+    // must — and does — render the same bits). The test is on the unnormalised cosine with a margin of 1e-3: the
+    // reference's own N.L, computed through two normalisations (:138, lights.h:49,83), differs from the true cosine by
+    // ~1e-6, so "clearly negative" here implies "negative" there.
+    if ((info & RTU_FI_SH) && s.nol_ok) {
+        const uint32_t nl = a.nsl < RTU_FI_NOL_LIGHTS ? a.nsl : RTU_FI_NOL_LIGHTS;
+        const float nn = dot3(N, N);
+        for (uint32_t j = 0; j < nl; j++) {
+            const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[j]];
+            const f3 lvec = ld3(l.vec);
+            const f3 tl = l.type == RTU_LIGHT_DIRECT ? -lvec : lvec - p;  // towards the light
+            const float c = dot3(N, tl), tt = dot3(tl, tl);
+            if (c < 0.0f && c * c > 1e-6f * (tt * nn) && tt > 1e-20f && tt < 1e30f) info |= 1u << (RTU_FI_NOL_SH + j);
+        }
+    }
     if (bounce > 0) {                                                   // :158
         if (not_black(mtl_color<TEXD>(s, mtl, RTU_MAP_REFRACTION, ld3(m.refraction), uvw))) {  // :160
             info |= RTU_FI_MAIN;
@@ -426,7 +445,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     }
     if (GID) return;
     uint32_t info = 0;
-    if (want) info = make_info<TEX>(s, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
+    if (want) info = make_info<TEX>(a, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
     if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
 }
 
@@ -557,6 +576,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     if (is_shadow) {
         // ---- shadow ray (lightFunctions.cpp:27-37, 43-65, 75-78; lights.h:48)
         if (!(sel & SEL_SHADOW) || !(info & RTU_FI_SH)) return false;
+        if (!STATS && slot < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + slot)) & 1u)) return false;  // behind the surface: its term is +-0 (make_info)
         const int li = a.shadow_light[slot];
         const RTU_CONST RtuLight& l = as_const(s.lights)[li];
         f3 lvec = ld3(l.vec);
@@ -833,7 +853,8 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
             float NDotH = dot3(N, halfVector);
             if (NDotL < 0.0f) NDotL = 0.0f;
             if (NDotH < 0.0f) NDotH = 0.0f;
-            const float sh = lv.fsh[(size_t)f * a.nsl + j];
+            const bool behind = !STATS && j < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + j)) & 1u);  // no shadow ray was fired (make_info)
+            const float sh = behind ? 1.0f : lv.fsh[(size_t)f * a.nsl + j];
             j++;
             f3 illum;
             if (isDirect) {
@@ -917,7 +938,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
                 cuvw = mk3(t.x, t.y, t.z);
                 nx.fuv[idx] = t;
             }
-            const uint32_t cinfo = make_info<TEX>(s, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp, GID && (info & RTU_FI_AMB));
+            const uint32_t cinfo = make_info<TEX>(a, cmid, bounce - 1, (packed[k] & 2u) != 0, cdir, cp, cN, cuvw, csmp, GID && (info & RTU_FI_AMB));
             nx.fa[idx] = make_float4(cp.x, cp.y, cp.z, __uint_as_float(cinfo));
             nx.fb[idx] = make_float4(cN.x, cN.y, cN.z, __uint_as_float(BATD ? entry : csmp.key));
             nx.fc[idx] = make_float4(cdir.x, cdir.y, cdir.z, GID ? fc.w : s0[k].w);  // recipe P: the chain id travels down
@@ -1204,8 +1225,8 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
         sa.key = child_key(sd.key, RTU_SLOT_AMBIENT_TREE);     // the tree lit by the AmbientLight (:569, :134)
         uint32_t ia = 0, id = 0;
         if (want) {
-            ia = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
-            id = make_info<TEX>(s, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
+            ia = make_info<TEX>(a, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
+            id = make_info<TEX>(a, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
         }
         Counters cnt = {};
         const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw, cnt);

@@ -1155,6 +1155,10 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ds.n_nodes = s->n_nodes;
     ds.walk_stack_limit = 0xFFFFu;
     ds.wscale = wscale;
+    ds.nol_ok = 1;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+        for (int k = 0; k < 3; k++)
+            if (!(std::fabs(s->lights[i].intensity[k]) < 1e15f)) ds.nol_ok = 0;
     ds.obj_mask = 0;
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
         if (s->nodes[i].obj_type != RTU_OBJ_NONE) ds.obj_mask |= 1ull << i;

@@ -99,6 +99,7 @@ struct DevScene {
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    wscale;            // largest |coordinate| of any node-level bound: the scale of the cull margin in world space
     unsigned long long obj_mask;  // bit k: node k (< 64) carries an object
+    uint32_t nol_ok, pad_nol;   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
     uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg
     uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
@@ -126,6 +127,8 @@ struct DevScene {
 #define RTU_FI_MAIN       (1u << 23)      // refraction property exists and bounce > 0 (:158-160)
 #define RTU_FI_TIR        (1u << 24)      // sinTheta2 > 1 (:205): the main ray is the TIR reflection
 #define RTU_FI_C          (1u << 25)      // reflection property exists and bounce > 0 (:273)
+#define RTU_FI_NOL_SH     27              // bits 27-31: non-ambient light j < 5 is behind the surface (N.L clearly negative): its term of the
+#define RTU_FI_NOL_LIGHTS 5u              //   light loop is exactly +-0 whatever Shadow() says, so the fast variant fires no shadow ray (make_info)
 #define RTU_FI_AMB        (1u << 26)      // recipe P: this Shade() tree receives MonteCarlo()'s one AmbientLight (LevelBuffers::famb) instead of the scene's lights
 
 // child status codes in fchild

@@ -598,6 +598,9 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
     // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches.
     const float4* bvh4 = mesh.bvh4;
     const float4* tris = mesh.fast.tri;
+    // (the mesh header is constant memory: left alone the compiler re-loads both pointers with a scalar load — and waits for it — in
+    // every step of the walk; pinned in vector registers they are loaded once)
+    asm volatile("" : "+v"(bvh4), "+v"(tris));
     const FastRay fr = fast_ray(ray, mesh.scale);
     // near / far plane arrays of a node, by the sign of the ray (see build_wide4)
     const uint32_t onx = fr.px ? 0u : 3u, ofx = 3u - onx, ony = fr.py ? 1u : 4u, ofy = 5u - ony, onz = fr.pz ? 2u : 5u, ofz = 7u - onz;

@@ -74,6 +74,13 @@ def render(scene, width, height, threads=1, row0=0, nrows=None):
     return out, st.as_dict()
 
 
+def debug_all_triangles(on):
+    """Test hook: the oracle tests every triangle of a mesh whatever its boxes say (not the reference's algorithm)."""
+    lib.rtu_oracle_debug_all_triangles.argtypes = [ctypes.c_int]
+    lib.rtu_oracle_debug_all_triangles.restype = None
+    lib.rtu_oracle_debug_all_triangles(1 if on else 0)
+
+
 def render_scheduled(scene, width, height, threads, per_pixel):
     """Recipe W, whole frame; per_pixel: the reference's PixelIterator schedule (one atomic fetch per pixel,
     PixelIterator.h:25-38) instead of chunks of rows. Same image, different scaling."""

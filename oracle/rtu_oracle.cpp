@@ -370,9 +370,18 @@ bool tri_hit(Ctx& cx, const RtuMesh& mesh, const Ray& ray, Hit& h, uint32_t face
     return false;
 }
 
+// Test hook (rtu_oracle_debug_all_triangles): every triangle of a mesh is tested, in element order, whatever the boxes say.
+// NOT the reference's algorithm — it exists to find rays for which the reference's own box arithmetic hides a triangle its
+// triangle test would accept (a ray clipping a box corner within rounding), so that tests can aim at them.
+static bool g_all_triangles = false;
+
 // TriObj::IntersectRay (objFunctions.cpp:333-406)
 bool mesh_hit(Ctx& cx, const RtuMesh& mesh, const Ray& ray, Hit& h) {
     bool hitResult = false;
+    if (g_all_triangles) {
+        for (uint32_t i = 0; i < mesh.n_elements; i++) hitResult |= tri_hit(cx, mesh, ray, h, mesh.elements[i]);
+        return hitResult;
+    }
     if (!box_hit(ray, ld3(mesh.bound_min), ld3(mesh.bound_max), RTU_BIGFLOAT)) return false;  // :337
     cx.st.mesh_entries++;
     static const int STACK_MAX = 256;  // reference: 100, overflow is UB there
@@ -1019,6 +1028,8 @@ void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* co
 uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx) { return rand31(key, idx); }
 uint32_t rtu_oracle_sample_key(uint32_t pixel, uint32_t sample) { return sample_key(pixel, sample); }
 uint32_t rtu_oracle_child_key(uint32_t key, uint32_t slot) { return child_key(key, slot); }
+
+void rtu_oracle_debug_all_triangles(int on) { g_all_triangles = on != 0; }
 
 int rtu_oracle_render_scheduled(const RtuSceneDesc* scene, int width, int height, float* rgbz_out, RtuOracleStats* stats, int threads,
                                 int per_pixel_schedule) {

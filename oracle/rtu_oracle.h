@@ -53,6 +53,8 @@ int  rtu_oracle_render_samples(const RtuSceneDesc* scene, int width, int height,
  * with 4 bounces and 1 sample, :549-590; cosine-weighted hemisphere sampling, :320-337). */
 int  rtu_oracle_render_paths(const RtuSceneDesc* scene, int width, int height, int row0, int nrows, int spp,
                              int stream, int trig, float* rgbz_out, RtuOracleStats* stats, int threads);
+/* Test hook: 1 = test every triangle of a mesh whatever its boxes say (NOT the reference's algorithm; see rtu_oracle.cpp). */
+void rtu_oracle_debug_all_triangles(int on);
 void rtu_oracle_portable_sincos(const float* t, int n, float* sin_out, float* cos_out);
 void rtu_oracle_portable_acos(const float* x, int n, float* out);
 uint32_t rtu_oracle_rand31(uint32_t key, uint32_t idx);

@@ -587,6 +587,37 @@ __device__ __forceinline__ FastRay fast_ray_world(const Ray& ray, float sceneSca
     return f;
 }
 
+// THE ONE WAY THE TREES COULD DISAGREE, closed. The fast tree's boxes are conservative, so its walk tests every triangle the
+// reference's walk tests — and possibly one more: a triangle the reference never reaches because ITS OWN box arithmetic
+// (BVHBoxIntersection, objFunctions.cpp:408-522, on the triangle's leaf or an ancestor, or :337 on the mesh's box) rejects a
+// ray that clips the box within rounding, although the triangle test would accept the hit. Every box the reference tests on
+// the way to a triangle CONTAINS the triangle's own bounding box B, and its slab test passes iff entry_i <= exit_j for every
+// pair of axes i != j (the same axis always passes: both bounds come from one monotone division). Those intervals only
+// widen from B to its ancestors. So: if the ray passes B with entry_i + m_i <= exit_j - m_j for all i != j, where
+// m_k = 1e-5 * max(scale, |origin|) / |dir_k| is 50 x the rounding of a slab bound (~2e-7 * (|bound| + |origin|) / |dir_k|),
+// the reference has certainly reached the triangle. If not, the ray is ambiguous and is re-walked on the reference's tree
+// like an exact tie. Checked for the triangle a walk is about to report (the closest hit, or a shadow ray's occluder).
+__device__ __forceinline__ bool reaches_like_the_reference(const float* v, const uint32_t* fv, const Ray& ray, float meshScale) {
+    const f3 A = ld3(v + 3 * fv[0]), B = ld3(v + 3 * fv[1]), C = ld3(v + 3 * fv[2]);
+    const f3 lo = mk3(fminf(A.x, fminf(B.x, C.x)), fminf(A.y, fminf(B.y, C.y)), fminf(A.z, fminf(B.z, C.z)));
+    const f3 hi = mk3(fmaxf(A.x, fmaxf(B.x, C.x)), fmaxf(A.y, fmaxf(B.y, C.y)), fmaxf(A.z, fmaxf(B.z, C.z)));
+    const float pm = fmaxf(fabsf(ray.p.x), fmaxf(fabsf(ray.p.y), fabsf(ray.p.z)));
+    const float delta = 1e-5f * (meshScale > pm ? meshScale : pm);
+    const float tiny = 0x1p-100f;
+    const float dx = fabsf(ray.dir.x) < tiny ? copysignf(tiny, ray.dir.x) : ray.dir.x;
+    const float dy = fabsf(ray.dir.y) < tiny ? copysignf(tiny, ray.dir.y) : ray.dir.y;
+    const float dz = fabsf(ray.dir.z) < tiny ? copysignf(tiny, ray.dir.z) : ray.dir.z;
+    const float rx = __builtin_amdgcn_rcpf(dx), ry = __builtin_amdgcn_rcpf(dy), rz = __builtin_amdgcn_rcpf(dz);
+    const float mx = delta * fabsf(rx), my = delta * fabsf(ry), mz = delta * fabsf(rz);
+    const float x0 = (lo.x - ray.p.x) * rx, x1 = (hi.x - ray.p.x) * rx;
+    const float y0 = (lo.y - ray.p.y) * ry, y1 = (hi.y - ray.p.y) * ry;
+    const float z0 = (lo.z - ray.p.z) * rz, z1 = (hi.z - ray.p.z) * rz;
+    const float ex = fminf(x0, x1) + mx, fx = fmaxf(x0, x1) - mx;  // entry pushed later, exit pulled earlier
+    const float ey = fminf(y0, y1) + my, fy = fmaxf(y0, y1) - my;
+    const float ez = fminf(z0, z1) + mz, fz = fmaxf(z0, z1) - mz;
+    return ex <= fminf(fy, fz) && ey <= fminf(fx, fz) && ez <= fminf(fx, fy);  // NaN anywhere: false -> the reference's tree decides
+}
+
 // The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
 // the order only affects speed: an exact tie between two accepted triangles, the one case where
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
@@ -679,6 +710,7 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
             }
         }
     }
+    if (hitResult && !tie && !reaches_like_the_reference(mesh.v, mesh.f + 3 * mesh.fast.elements[win.slot], ray, mesh.scale)) tie = true;
     if (hitResult && !shadow && !tie) {
         RTU_TOUCH(t_win, 1);
         const uint32_t face = mesh.fast.elements[win.slot];
@@ -851,6 +883,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
             }
         }
     }
+    if (hitResult && !tie && !reaches_like_the_reference(mesh.v, mesh.f + 3 * mesh.fast.elements[win.slot], ray, mesh.scale)) tie = true;  // group-uniform
     if (tie) {  // redo this ray on the reference's tree, one lane per ray (all eight lanes identically)
         h = h0;
         bool t2 = false;

@@ -774,3 +774,58 @@ def test_node_level_bounds_on_adversarial_rays(pkg, orc, tmp_path):
         check_against(fast, cpu, orc)
     finally:
         ctx.close()
+
+
+def test_rays_grazing_bounding_boxes_edge_on(pkg, orc, tmp_path):
+    """The one way the fast tree and the reference's tree could disagree: a ray that clips a bounding box within rounding, so
+    that the reference's own box arithmetic never reaches a triangle its triangle test would accept (rtu_intersect.h:
+    reaches_like_the_reference). Constructed: an axis-aligned mesh (flat boxes, edges and vertices lying in box faces) under
+    a transformation, seen through cameras zoomed by up to 10^7 onto a box edge, a box corner and a vertex shared by six
+    triangles — every primary ray and every shadow ray of these images passes a box boundary within a few ulp. The detector
+    must fire (walks finished on the reference's tree show in the touched-bytes counters) and the fast variant must equal
+    the counting variant (the reference's walk) bit for bit, and the oracle."""
+    obj = tmp_path / "steps.obj"
+    n = 6
+    verts = [(i * 0.5 - 1.5, j * 0.5 - 1.5, 0.25 * ((i + j) % 3)) for i in range(n + 1) for j in range(n + 1)]
+    vid = lambda i, j: i * (n + 1) + j + 1
+    faces = []
+    for i in range(n):
+        for j in range(n):
+            faces += [(vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)), (vid(i, j), vid(i + 1, j + 1), vid(i, j + 1))]
+    obj.write_text("".join("v %r %r %r\n" % v for v in verts) + "".join("f %d %d %d\n" % f for f in faces))
+    sx, tx, ty, tz = 1.37, 0.11, -0.07, 0.013
+    world = lambda v: (v[0] * sx + tx, v[1] * sx + ty, v[2] * sx + tz)
+    targets = [world(verts[0]),                      # a corner of the mesh's bounding box
+               world((-1.5, 0.25, 0.0)),             # a point of the box's x-min edge
+               world(verts[vid(3, 3) - 1]),          # a vertex shared by six triangles, inside
+               world((0.25, 0.25, 0.25))]            # a point of an interior edge
+    W, H = 256, 48
+    ctx = pkg.Context(0)
+    fired = 0
+    try:
+        for tgt in targets:
+            for fov, cam_off in ((1e-3, (0.0, 0.0, 9.0)), (3e-5, (0.4, -0.3, 7.0)), (3e-6, (0.0, 0.0, 11.0)), (1e-5, (6.0, 5.0, 0.0013))):
+                xml = tmp_path / "graze.xml"
+                xml.write_text("""<xml><scene><object type="obj" name="%s" material="m"><scale value="%r"/><translate x="%r" y="%r" z="%r"/></object>
+                  <material type="blinn" name="m"><diffuse r="0.7" g="0.6" b="0.5"/><specular value="0.3"/></material>
+                  <light type="ambient" name="a"><intensity value="0.3"/></light>
+                  <light type="point" name="p"><intensity value="30"/><position x="%r" y="%r" z="%r"/></light></scene>
+                  <camera><position x="%r" y="%r" z="%r"/><target x="%r" y="%r" z="%r"/><up x="0" y="1" z="0.01"/><fov value="%r"/>
+                  <width value="%d"/><height value="%d"/></camera></xml>""" % (
+                    obj, sx, tx, ty, tz, tgt[0] + 2.0, tgt[1] - 1.0, tgt[2] + 4.0,
+                    tgt[0] + cam_off[0], tgt[1] + cam_off[1], tgt[2] + cam_off[2], tgt[0], tgt[1], tgt[2], fov, W, H))
+                scene = pkg.Scene.from_xml(str(xml))
+                ctx.upload(scene)
+                cpu, cst = orc.render(scene, W, H, threads=8)
+                cnt, gst = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+                assert gst == cst
+                for coop in (1, 10 ** 9):
+                    fr = pkg.frame_setup(scene.desc.camera, W, H, collect_stats=2)
+                    fr.coop_threshold = coop
+                    fast, _ = ctx.render(fr)
+                    assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "fast and counting variants differ (fov %g)" % fov
+                    fired += sum(c["inner_ref"] for c in ctx.touched().values())
+                check_against(fast, cpu, orc)
+    finally:
+        ctx.close()
+    assert fired > 0, "no ray was ambiguous: the scene does not exercise the detector"

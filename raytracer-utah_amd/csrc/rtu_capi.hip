@@ -894,17 +894,21 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
                 int rc = launch(ctx, frame, ctx->sample_buf, stream, zero_counters && i == 0 && k == 0, i, nb, nullptr, RTU_LAUNCH_CHAIN, k);
                 if (rc != RTU_OK) return rc;
             }
-            for (int k = RTU_GI_BOUNCES; k >= 0; k--) {
-                for (;;) {
+            // the five shading steps are queued back to back; ONE host synchronisation per batch reads the (sticky) overflow
+            // report of all of them. A batch that ran out of frame records is shaded again from the deepest depth with the
+            // grown capacities: its chain records do not depend on them.
+            for (;;) {
+                for (int k = RTU_GI_BOUNCES; k >= 0; k--) {
                     int rc = launch(ctx, frame, ctx->sample_buf, stream, false, i, nb, nullptr, RTU_LAUNCH_SHADE, k);
                     if (rc != RTU_OK) return rc;
-                    RTU_HIP(ctx, hipStreamSynchronize(stream));
-                    bool overflow = false;
-                    if ((rc = check_overflow(ctx, &overflow)) != RTU_OK) return rc;
-                    if (!overflow) break;  // (a repeated step reads the same chain records and results of depth k + 1)
-                    if (frame->collect_stats) return fail(ctx, RTU_ERR_CAPACITY, "recipe P with counters: frame records ran out; render once without counters first");
-                    if (++rounds > 8 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
                 }
+                RTU_HIP(ctx, hipStreamSynchronize(stream));
+                bool overflow = false;
+                int rc = check_overflow(ctx, &overflow);
+                if (rc != RTU_OK) return rc;
+                if (!overflow) break;
+                if (frame->collect_stats) return fail(ctx, RTU_ERR_CAPACITY, "recipe P with counters: frame records ran out; render once without counters first");
+                if (++rounds > 8 * RTU_MAX_LEVELS) return fail(ctx, RTU_ERR_CAPACITY, "recursion frames still exceed the capacity after %d rounds", rounds);
             }
         }
         hipError_t e = (hipError_t)rtu_launch_accumulate(ctx->sample_buf, (uint32_t)nb, ctx->acc, ctx->acc_hits, (uint32_t)pixels, i == 0, stream);

@@ -241,3 +241,46 @@ def test_begin_render_paths_dropin(pkg, orc, golden, tmp_path):
     if png.ndim == 2:
         png = np.repeat(png[..., None], 3, axis=2)
     assert np.abs(png.astype(np.int32) - c8.astype(np.int32)).max() <= RGB8_TOL
+
+
+def test_config5_at_its_own_size(pkg, orc, ctx, golden):
+    """BASELINE config 5 at size: Project11 @1920x1080, recipe P (sample loop + 4-bounce Monte-Carlo gather), 4 samples per
+    pixel — 8.3 M chains, 33 M shadow rays. Against the committed fixture (every 8th pixel of the oracle's frame on the keyed
+    streams, tests/golden/make_oracle_goldens.py): z bit-exact, 8-bit RGB within one level, linear RGB to 1e-3; the sha256 of
+    the whole float z; against the oracle run here on every pixel; the counting variant renders the same bits with the
+    oracle's counters; properties that do not depend on any oracle: a second render is bit-identical (keyed streams), and the
+    16-spp frame is closer to the 64-spp frame than the 4-spp one (the estimator converges)."""
+    import hashlib, json, os
+    g = golden("p11_1080")
+    scene = g.scene(pkg)
+    W, H = g.width, g.height
+    fx = golden("p11_p4_1080")
+    spp = fx.meta["spp"]
+    gpu = render_paths_gpu(pkg, ctx, scene, W, H, spp)
+    assert hashlib.sha256(np.ascontiguousarray(gpu[..., 3]).tobytes()).hexdigest() == fx.meta["sha256_z_f32"], "z differs from the fixture"
+    assert np.array_equal(gpu[::8, ::8, 3].view(np.uint32), fx.npz["z_sub8"].view(np.uint32))
+    ref = fx.npz["rgb_sub8"].astype(np.float64)
+    d = np.abs(gpu[::8, ::8, :3].astype(np.float64) - ref)
+    assert (d / np.maximum(np.abs(ref), 1e-2)).max() < 1e-3, "linear RGB differs from the fixture"
+    again = render_paths_gpu(pkg, ctx, scene, W, H, spp)
+    assert np.array_equal(again.view(np.uint32), gpu.view(np.uint32)), "two renders of the same frame differ"
+    # every pixel against the oracle run on this machine
+    cpu, cst = orc.render_paths(scene, W, H, spp, stream=orc.STREAM_KEYED, trig=orc.TRIG_PORTABLE, threads=min(64, os.cpu_count() or 8))
+    assert np.array_equal(gpu[..., 3].view(np.uint32), cpu[..., 3].view(np.uint32)), "z differs"
+    g8, _, gz8 = orc.postprocess(gpu)
+    c8, _, cz8 = orc.postprocess(cpu)
+    assert np.array_equal(gz8, cz8)
+    d8 = np.abs(g8.astype(np.int32) - c8.astype(np.int32))
+    assert d8.max() <= RGB8_TOL, "8-bit RGB differs by %d levels at %d pixels" % (d8.max(), (d8 > RGB8_TOL).sum())
+    frs = pkg.frame_setup(scene.desc.camera, W, H, samples=spp, gather_bounces=4, collect_stats=True)
+    cnt, gst = ctx.render(frs, stats=True)
+    assert np.array_equal(cnt.view(np.uint32), gpu.view(np.uint32)), "fast and counting variants differ"
+    assert gst == cst, "counters differ"
+    assert (gst["primary_rays"], gst["shadow_rays"]) == (fx.meta["primary"], fx.meta["shadow"])
+    # convergence
+    g16 = render_paths_gpu(pkg, ctx, scene, W, H, 16)
+    g64 = render_paths_gpu(pkg, ctx, scene, W, H, 64)
+    e4 = np.abs(gpu[..., :3] - g64[..., :3]).mean()
+    e16 = np.abs(g16[..., :3] - g64[..., :3]).mean()
+    assert e16 < 0.75 * e4, (e4, e16)
+    assert np.array_equal((g64[..., 3] < 1e29), (gpu[..., 3] < 1e29).__or__(g64[..., 3] < 1e29))  # a pixel hit at 4 spp is hit at 64

@@ -99,6 +99,9 @@ RtuRenderJob* rtu_begin_render_paths(const RtuScene* scene, RtuImage* img,
                                      const char* result_png, const char* zbuffer_png);
 void      rtu_stop_render(RtuRenderJob* job);      /* cooperative cancel between bands */
 int       rtu_render_wait(RtuRenderJob* job);      /* join; 0 or negative error code */
+/* After the job (joins): how the shards reached the host — 1 one context; 2 several contexts, asynchronous copies into one
+ * pinned buffer, all in flight together; 3 RCCL (grouped ncclSend / ncclRecv to the root GPU, then one copy). */
+int       rtu_render_gather_kind(RtuRenderJob* job);
 void      rtu_render_job_free(RtuRenderJob* job);
 
 #ifdef __cplusplus

@@ -268,6 +268,15 @@ int  rtu_selftest_primitives(RtuContext* ctx, unsigned long long n_rays, unsigne
                              unsigned long long* mismatches_out);
 
 /* Device memory helpers so a C/C++ host needs no HIP headers. */
+/* The context's own stream (a hipStream_t as void*) and device: a multi-GPU host (host/begin_render.cpp) renders every shard on
+ * its context's stream and queues the collection — RCCL send / receive or an asynchronous copy into pinned host memory — behind
+ * it on the same stream, so that the shards of all GPUs travel at the same time. */
+void* rtu_context_stream(RtuContext* ctx);
+int   rtu_context_device(const RtuContext* ctx);
+int   rtu_context_sync(RtuContext* ctx);                       /* wait for the context's stream */
+void* rtu_host_alloc_pinned(size_t bytes);                     /* page-locked host memory (asynchronous copies need it) */
+void  rtu_host_free_pinned(void* p);
+int   rtu_copy_to_host_async(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes, void* hip_stream);
 void* rtu_device_alloc(RtuContext* ctx, size_t bytes);
 void  rtu_device_free(RtuContext* ctx, void* d_ptr);
 int   rtu_copy_to_host(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes);

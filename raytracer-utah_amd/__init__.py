@@ -141,7 +141,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -188,7 +188,7 @@ HOST_SYMBOLS = ["rtu_scene_load_xml", "rtu_scene_clone", "rtu_scene_load_blob", 
                 "rtu_image_free", "rtu_image_width", "rtu_image_height", "rtu_image_pixels", "rtu_image_zbuffer",
                 "rtu_image_zimage", "rtu_image_num_rendered", "rtu_image_is_done", "rtu_image_from_rgbz",
                 "rtu_image_compute_zimg", "rtu_image_save_png", "rtu_image_save_zpng", "rtu_write_png",
-                "rtu_begin_render", "rtu_begin_render_sampled", "rtu_begin_render_paths", "rtu_stop_render", "rtu_render_wait", "rtu_render_job_free"]
+                "rtu_begin_render", "rtu_begin_render_sampled", "rtu_begin_render_paths", "rtu_stop_render", "rtu_render_wait", "rtu_render_gather_kind", "rtu_render_job_free"]
 _sig(host, "rtu_scene_load_xml", _P, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
 _sig(host, "rtu_scene_clone", _P, _P)
 _sig(host, "rtu_scene_load_blob", _P, _P, ctypes.c_size_t)
@@ -219,6 +219,7 @@ _sig(host, "rtu_begin_render_sampled", _P, _P, _P, ctypes.POINTER(_I), _I, _I, c
 _sig(host, "rtu_begin_render_paths", _P, _P, _P, ctypes.POINTER(_I), _I, _I, ctypes.c_char_p, ctypes.c_char_p)
 _sig(host, "rtu_stop_render", None, _P)
 _sig(host, "rtu_render_wait", _I, _P)
+_sig(host, "rtu_render_gather_kind", _I, _P)
 _sig(host, "rtu_render_job_free", None, _P)
 
 

@@ -1597,6 +1597,34 @@ void rtu_device_free(RtuContext* ctx, void* d_ptr) {
     (void)hipFree(d_ptr);
 }
 
+void* rtu_context_stream(RtuContext* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rtu_context_device(const RtuContext* ctx) { return ctx ? ctx->device : -1; }
+
+int rtu_context_sync(RtuContext* ctx) {
+    if (!ctx) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RTU_OK;
+}
+
+void* rtu_host_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void rtu_host_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int rtu_copy_to_host_async(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes, void* hip_stream) {
+    if (!ctx || !h_dst || !d_src) return RTU_ERR_ARG;
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    RTU_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    return RTU_OK;
+}
+
 int rtu_copy_to_host(RtuContext* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (!ctx || !h_dst || !d_src) return RTU_ERR_ARG;
     RTU_HIP(ctx, hipSetDevice(ctx->device));

@@ -3,6 +3,7 @@ oracle on the same inputs and against the goldens generated from the compiled
 reference. Bars: float z bit-exact (hence ZBuffer.png exact), 8-bit RGB
 within +-1 per channel (device powf/expf vs glibc), ray / traversal counters equal."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -241,6 +242,48 @@ def test_begin_render_dropin(pkg, orc, golden, tmp_path):
     assert np.array_equal(zimg, g.npz["zbuffer_u8"])
     rgb = read_png(rp)
     assert np.abs(rgb.astype(np.int32) - g.npz["result_u8"].astype(np.int32)).max() <= RGB8_TOL
+
+
+@pytest.mark.parametrize("tag,n_ctx", [("teapot2_240x135", 3), ("p4_240x135", 2), ("teapot2_1080", 3), ("p13_200x150", 5)])
+def test_begin_render_on_several_contexts(pkg, golden, tag, n_ctx, tmp_path):
+    """The N-device code of the C++ drop-in (host/begin_render.cpp: main.cpp:29-64's SpawnRenderThreads over GPUs) on the one-GPU
+    box: device_ids = {0, 0, ...} makes N contexts on GPU 0, each rendering its interleaved 8-row bands on its own stream,
+    collected by asynchronous copies that are all in flight together (RCCL needs N distinct GPUs: with duplicates the job takes
+    the copy path and says so). The PNGs must be the reference's: ZBuffer.png exact, Result.png within one level."""
+    from conftest import read_png
+    g = golden(tag)
+    scene = g.scene(pkg)
+    img = pkg.Image(g.width, g.height)
+    devs = (ctypes.c_int * n_ctx)(*([0] * n_ctx))
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    job = pkg.host.rtu_begin_render(scene._h, img._h, devs, n_ctx, rp.encode(), zp.encode())
+    assert job
+    assert pkg.host.rtu_render_wait(job) == 0, pkg.host.rtu_host_last_error()
+    assert pkg.host.rtu_render_gather_kind(job) == 2
+    pkg.host.rtu_render_job_free(job)
+    assert pkg.host.rtu_image_is_done(img._h)
+    assert np.array_equal(read_png(zp), read_png(os.path.join(g.dir, "ZBuffer.png")))
+    ref = read_png(os.path.join(g.dir, "Result.png"))
+    assert np.abs(read_png(rp).astype(np.int32) - ref.astype(np.int32)).max() <= RGB8_TOL
+
+
+def test_begin_render_rccl_path_loads_and_runs(pkg, golden, tmp_path, monkeypatch):
+    """The RCCL branch of the drop-in needs as many distinct GPUs as contexts; on the one-GPU box RTU_FORCE_RCCL sends a single
+    context through it: librccl.so is found and its entry points resolved at run time, a communicator is created on the GPU,
+    the (empty) send / receive group is issued on the context's stream, the frame arrives through the same copies."""
+    from conftest import read_png
+    monkeypatch.setenv("RTU_FORCE_RCCL", "1")
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    img = pkg.Image(g.width, g.height)
+    devs = (ctypes.c_int * 1)(0)
+    rp, zp = str(tmp_path / "Result.png"), str(tmp_path / "ZBuffer.png")
+    job = pkg.host.rtu_begin_render(scene._h, img._h, devs, 1, rp.encode(), zp.encode())
+    assert job
+    assert pkg.host.rtu_render_wait(job) == 0, pkg.host.rtu_host_last_error()
+    assert pkg.host.rtu_render_gather_kind(job) == 3, "the RCCL path was not taken"
+    pkg.host.rtu_render_job_free(job)
+    assert np.array_equal(read_png(zp), g.npz["zbuffer_u8"])
 
 
 def test_exact_ties_follow_the_reference_order(pkg, orc, ctx, tmp_path):

@@ -188,8 +188,10 @@ int  rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_
 /* Test hook for the tail kernel. Recursion levels that were almost empty in the previous frame of a
  * scene are not launched kernel by kernel in the next one: one kernel evaluates every frame of the
  * first such level, subtree and all, with one wavefront per frame. Which level that is
- * comes from the previous frame's counts and is only a hint — any value renders the same image.
- * This sets it for the next frame: 1..5, or 6 for "no tail". */
+ * comes from the counts of the previous launch of the same shape and is only a hint — any value renders the same image; if the
+ * level turns out to hold thousands of frames (the view changed) the kernel refuses it on the device, the frame is reported
+ * incomplete like a capacity overflow (rtu_frame_status) and rendered again level by level.
+ * This sets the cut level for the NEXT launch only (taken as it is, never refused): 1..5, or 6 for "no tail". */
 int  rtu_debug_tail_from(RtuContext* ctx, int level);
 
 /* Test hook: switch the node-level bounds of the fast variant off (0) or on (1, the default after an upload) until the next

@@ -58,7 +58,9 @@ namespace {
 #define CNTD ((TEX & 16) != 0)
 // occupancy hints per kernel family (amdgpu_waves_per_eu), see DESIGN.md 5 for what was measured
 #ifndef RTU_OCC_PRIMARY
-#define RTU_OCC_PRIMARY
+// k_primary: six wavefronts per SIMD (<= 85 VGPRs) — the tile loop left alone takes 97 and fits five: 335 us per 16 frames against 304;
+// eight (64 VGPRs, spills): 350. k_trace / k_consume at six and the stage-2 walks at four (from five / three): slower or no change.
+#define RTU_OCC_PRIMARY __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
 #ifndef RTU_OCC_TRACE
 #define RTU_OCC_TRACE
@@ -176,9 +178,8 @@ __device__ __forceinline__ uint32_t make_info(const KernelArgs& a, int mtl, int 
         const uint32_t nl = a.nsl < RTU_FI_NOL_LIGHTS ? a.nsl : RTU_FI_NOL_LIGHTS;
         const float nn = dot3(N, N);
         for (uint32_t j = 0; j < nl; j++) {
-            const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[j]];
-            const f3 lvec = ld3(l.vec);
-            const f3 tl = l.type == RTU_LIGHT_DIRECT ? -lvec : lvec - p;  // towards the light
+            const f3 lvec = ld3(a.nol_light[j]);
+            const f3 tl = a.nol_light[j][3] != 0.0f ? -lvec : lvec - p;  // towards the light
             const float c = dot3(N, tl), tt = dot3(tl, tl);
             if (c < 0.0f && c * c > 1e-6f * (tt * nn) && tt > 1e-20f && tt < 1e30f) info |= 1u << (RTU_FI_NOL_SH + j);
         }
@@ -1106,6 +1107,16 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
     const uint32_t nslots = a.nsl + 3u;
     const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
     const uint32_t roots = level_max_count(a, Ls) * RTU_SHARDS;  // (index within shard, shard) slots
+    {   // the cut level is the host's guess from an earlier frame. A wavefront per subtree is right for a few hundred of them and
+        // a hundred times too slow for a million: refuse those, the host renders the frame again level by level.
+        uint32_t total = shard_count(a, Ls, lane % RTU_SHARDS);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += (uint32_t)__shfl_xor((int)total, off);
+        if (total > RTU_TAIL_DECLINE && !(a.dbg & 128u)) {
+            if (blockIdx.x == 0 && lane == 0) a.fcnt->tail_declined = 1;
+            return;
+        }
+    }
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < roots; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, rfl = c / RTU_SHARDS;
@@ -1302,7 +1313,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     // workgroups, so the deeper, usually sparse levels get smaller grids
     // (measured with 16 frames in flight: 32768 instead of 8192 workgroups for the one-lane-per-ray stage 2 and 4096
     // instead of 2048 for k_consume balance the chunks better, -8 %; a single frame is unchanged)
-    const dim3 gridT(8192), gridN(32768), gridS(8192), gridF(4096), gridC(1024), gridCoop(512);
+    // (round 2, counters on lines of their own: 32768 workgroups for k_trace(L0) 135 -> 125 us, 16384 for k_consume(L0) 134 -> 109 us;
+    // 16384 or 65536 instead of 32768 for the one-lane-per-ray stage 2: +3 % / +1 %)
+    const dim3 gridT(32768), gridN(32768), gridS(8192), gridF0(16384), gridF(4096), gridC(1024), gridCoop(512);
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
     const uint32_t blocksP = (n_tiles + 3) / 4;
@@ -1338,7 +1351,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
                 RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a, L, sel, ph);
                 RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, a, L, sel, ph);
             }
-            RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), gridF, block, a, L);
+            RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);
         }
     }
     if (regular < levels) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * regular, (k_tail<TEX>), dim3(8192), block, a, regular);

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -53,11 +54,14 @@ struct RtuContext {
     bool      want_gi = false;           // level buffers carry famb
     // k_tail: the recursion level from which the previous frame of this scene was almost empty (a hint —
     // any value renders the same image); last_tail_from: what the most recent frame was launched with
-    int      tail_hint = RTU_MAX_LEVELS, last_tail_from = RTU_MAX_LEVELS;
+    int      tail_hint = 0, last_tail_from = RTU_MAX_LEVELS;   // tail_hint: set by rtu_debug_tail_from for the next launch (0: none)
+    std::map<uint64_t, int> tail_hints;   // per launch shape (tiles of the launch, feature set): learned cut level
+    uint64_t last_tail_key = 0;
     bool     last_stats = false;
     uint32_t n_meshes = 0;
     uint32_t nsl = 0;
     int32_t  shadow_light[RTU_MAX_SHADOW_LIGHTS] = {};
+    float    nol_light[RTU_FI_NOL_LIGHTS][4] = {};
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
     unsigned long long* counters = nullptr;  // 11 x u64 (RtuStats), or the touched-bytes table [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]
@@ -732,7 +736,16 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
-    a.tail_from = stats == 1 ? RTU_MAX_LEVELS : ctx->tail_hint;
+    // the cut level for k_tail: what a launch of the same shape showed last time (a hint: any value renders the same image, a
+    // wrong one is refused on the device and reported like an overflow); rtu_debug_tail_from overrides it once
+    const uint64_t tail_key = ((uint64_t)n_tiles << 8) | (uint64_t)((frame->samples ? 2 : 0) | (frames_batch ? 4 : 0) | (gi ? 8 : 0));
+    int hint = RTU_MAX_LEVELS;
+    bool forced = false;
+    if (ctx->tail_hint != 0) { hint = ctx->tail_hint; ctx->tail_hint = 0; forced = true; }
+    else if (ctx->tail_hints.count(tail_key)) hint = ctx->tail_hints[tail_key];
+    a.tail_from = stats == 1 ? RTU_MAX_LEVELS : hint;
+    ctx->last_tail_key = tail_key;
+    if (forced) a.dbg |= 128u;  // a cut level set by the test hook is taken as it is (k_tail does not refuse it)
     if (frame->samples >= 1) {
         const float pixelIncrement = (float)(1.0 / frame->samples);  // RenderFunctions.cpp:68
         a.sampling = 1;
@@ -768,6 +781,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
+    memcpy(a.nol_light, ctx->nol_light, sizeof a.nol_light);
     if (gi_mode == RTU_LAUNCH_SHADE && gi_depth == 0) {
         hipError_t e0 = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
         if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
@@ -791,8 +805,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 // After the stream has drained: did any recursion level run out of frame capacity?
 // Frames per level of the frame just finished -> where k_tail may take over in the next one.
 void learn_tail(RtuContext* ctx, const FrameCounters& h) {
-    const uint32_t kTailMax = 256;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
-                                    // wavefront by wavefront are slower than their levels kernel by kernel
+    const uint32_t kTailMax = RTU_TAIL_LEARN;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
+                                               // wavefront by wavefront are slower than their levels kernel by kernel
     uint32_t frames[RTU_MAX_LEVELS];
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         frames[L] = 0;
@@ -803,8 +817,8 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
     int hint = RTU_MAX_LEVELS;
     for (int L = 1; L <= top; L++)
         if (frames[L] <= kTailMax) { hint = L; break; }
-    if (hint == RTU_MAX_LEVELS && used < RTU_MAX_LEVELS) hint = used + 1 < RTU_MAX_LEVELS ? used + 1 : RTU_MAX_LEVELS;
-    ctx->tail_hint = hint;
+    // the launch had a tail and its cut level was not small after all: deeper counts are unknown, learn them from a launch without
+    ctx->tail_hints[ctx->last_tail_key] = hint;
 }
 
 // The append counters keep counting past the capacity, so an overflowed frame tells how much its
@@ -814,12 +828,14 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
     FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
-    *overflow = h.overflow != 0;
+    *overflow = h.overflow != 0 || h.tail_declined != 0;
     if (!*overflow) {
         learn_tail(ctx, h);
         return RTU_OK;
     }
-    RTU_HIP(ctx, hipMemset(&ctx->fcnt->overflow, 0, sizeof(uint32_t)));  // reported: the next status starts clean
+    RTU_HIP(ctx, hipMemset(&ctx->fcnt->overflow, 0, 2 * sizeof(uint32_t)));  // reported: the next status starts clean (overflow, tail_declined)
+    if (h.tail_declined) ctx->tail_hints[ctx->last_tail_key] = RTU_MAX_LEVELS;  // this shape is rendered level by level from now on
+    if (!h.overflow) return RTU_OK;  // nothing ran out of capacity: render again, that is all
     bool grew = false;
     for (int L = 1; L < RTU_MAX_LEVELS; L++) {
         uint32_t need = 0;
@@ -1179,10 +1195,17 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ctx->dscene = ds;
     ctx->nsl = 0;
     for (uint32_t i = 0; i < s->n_lights; i++)
-        if (s->lights[i].type != RTU_LIGHT_AMBIENT) ctx->shadow_light[ctx->nsl++] = (int32_t)i;
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT) {
+            if (ctx->nsl < RTU_FI_NOL_LIGHTS) {
+                for (int k = 0; k < 3; k++) ctx->nol_light[ctx->nsl][k] = s->lights[i].vec[k];
+                ctx->nol_light[ctx->nsl][3] = s->lights[i].type == RTU_LIGHT_DIRECT ? 1.0f : 0.0f;
+            }
+            ctx->shadow_light[ctx->nsl++] = (int32_t)i;
+        }
     memset(ctx->want_cap_s, 0, sizeof ctx->want_cap_s);
     ctx->want_defer_s = 0;
-    ctx->tail_hint = RTU_MAX_LEVELS;
+    ctx->tail_hint = 0;
+    ctx->tail_hints.clear();
     ctx->n_meshes = s->n_meshes;
     ctx->mesh_info = mesh_info;
     ctx->any_recursive_material = false;
@@ -1417,7 +1440,7 @@ int rtu_frame_status(RtuContext* ctx) {
     int rc = check_overflow(ctx, &overflow);
     if (rc != RTU_OK) return rc;
     if (overflow) {
-        return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity; render the frame again");
+        return fail(ctx, RTU_ERR_CAPACITY, "recursion frames exceeded the provisioned capacity (or the tail kernel refused its cut level); render the frame again");
     }
     return RTU_OK;
 }

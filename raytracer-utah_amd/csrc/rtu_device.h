@@ -172,6 +172,8 @@ struct LevelBuffers {
 #define RTU_LDS_NODE_F4  ((RTU_LDS_BYTES - RTU_COOP_GROUPS * RTU_STACK8 * 4) / 16)
 
 #define RTU_SHARDS 64
+#define RTU_TAIL_LEARN   256u   // the host hands levels to k_tail when the cut level held at most this many frames last time
+#define RTU_TAIL_DECLINE 4096u  // ... and k_tail refuses a cut level with more than this many (the hint was for another view)
 #define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_impl.h)
 #define RTU_TOUCH_FIELDS 11  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
 #define RTU_TOUCH_STRIDE 16  // u64 per timeline slot in the counter table of the touched-bytes mode
@@ -190,7 +192,9 @@ struct FrameCounters {
     uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];      // entries of lmain / lrefl
     uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more (sticky: rtu_frame_status)
-    uint32_t pad[31];
+    uint32_t tail_declined;  // k_tail found more frames at its cut level than it takes (RTU_TAIL_DECLINE): it evaluated nothing, the frame
+                             // is incomplete and must be rendered again without the tail (sticky, reported like an overflow)
+    uint32_t pad[30];
 };
 
 struct BatchCam {
@@ -213,6 +217,7 @@ struct KernelArgs {
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights
     int32_t      shadow_light[RTU_MAX_SHADOW_LIGHTS];  // their indices in lights[]
+    float        nol_light[RTU_FI_NOL_LIGHTS][4];      // the first non-ambient lights {vec.xyz, 1 = direct}: make_info tests N.L without a dependent load
     uint32_t     n_meshes;
     int32_t      tail_from;         // recursion levels >= this are evaluated by k_tail (RTU_MAX_LEVELS: none)
     // recipe S (frame.samples >= 1): one launch sequence per sample

@@ -872,3 +872,48 @@ def test_rays_grazing_bounding_boxes_edge_on(pkg, orc, tmp_path):
     finally:
         ctx.close()
     assert fired > 0, "no ray was ambiguous: the scene does not exercise the detector"
+
+
+def test_tail_hint_from_another_view_is_refused_not_trusted(pkg, ctx, golden):
+    """The cut level of the tail kernel is a guess from the previous launch of the same shape. Project4 seen with the camera
+    turned by 30 degrees is a bare wall (no recursion at all: the guess becomes "everything below level 0 is tiny"); the next
+    frame, the scene's own view, has 390 000 frames at level 1 — one wavefront per subtree would take a hundred times the
+    frame. k_tail refuses such a cut level on the device; the frame is reported incomplete (RTU_ERR_CAPACITY from the
+    asynchronous entry, a transparent second render from the synchronous one), rendered again level by level, and is the
+    golden frame bit for bit."""
+    import importlib.util, time
+    spec = importlib.util.spec_from_file_location("rtu_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = golden("p4_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    wall = pkg.frame_setup(bench.orbit_camera(scene.desc.camera, 30.0), W, H)
+    view = pkg.frame_setup(scene.desc.camera, W, H)
+    d = pkg.hip.rtu_device_alloc(ctx._h, W * H * 16)
+    ctx.render_device(wall, d, None)
+    ctx.frame_status()
+    frames, _ = ctx.frame_counts()
+    assert frames[1] == 0, frames  # the premise: nothing below level 0 in this view
+    ctx.render_device(view, d, None)
+    with pytest.raises(pkg.RtuError) as e:
+        ctx.frame_status()
+    assert e.value.code == pkg.RTU_ERR_CAPACITY
+    t0 = time.perf_counter()
+    ctx.render_device(view, d, None)
+    ctx.frame_status()
+    assert time.perf_counter() - t0 < 0.05, "the second render still went through the tail kernel"
+    out = np.empty((H, W, 4), np.float32)
+    assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+    pkg.hip.rtu_device_free(ctx._h, d)
+    assert sha256(out[..., 3]) == g.meta["sha256_z_f32"]
+    # the synchronous entry on a fresh context: wall, then the view — one call, the right frame
+    c2 = pkg.Context(0)
+    try:
+        c2.upload(scene)
+        c2.render(wall)
+        img, _ = c2.render(view)
+        assert np.array_equal(img.view(np.uint32), out.view(np.uint32))
+    finally:
+        c2.close()

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--tag", default=WORKLOAD_TAG, help="golden tag to render (default: the headline workload)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (0 = every core this process may run on)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (0 = every core this process may use: its affinity mask, capped by the cgroup CPU quota)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
     ap.add_argument("--frames-in-flight", type=int, default=-1,
@@ -400,7 +400,23 @@ def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, threads, samples=0, p
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, threads if threads > 0 else avail)
+    # the cores this process may actually USE: a container's CPU quota (cgroup cpu.max) can be far below the threads it sees —
+    # the GPU box shows 256 hardware threads and grants the time of 16; more threads than that only contend
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // per))
+        except (OSError, ValueError):
+            pass
+    usable = min(avail, quota) if quota else avail
+    cores = max(1, threads if threads > 0 else usable)
 
     def timed(fn, budget):
         frames, t0 = 0, time.perf_counter()
@@ -427,7 +443,7 @@ def cpu_baseline(g, scene, W, H, rays_per_frame, budget_s, threads, samples=0, p
     rate_r, rate_p = rays_per_frame * fr / elr / 1e6, rays_per_frame * fp / elp / 1e6
     best_ms = min(elr / fr, elp / fp) * 1e3
     return {"value": round(max(rate_r, rate_p), 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "host_cores_available": avail,
+            "host_threads_visible": avail, "cpu_quota_cores": quota,
             "sample": "full %dx%d frames of the same workload (golden camera): 1 on 1 thread (%.3f Mrays/s), %d on %d threads in row chunks, "
                       "%d on %d threads with the reference's per-pixel atomic schedule (PixelIterator.h:25-38)" % (W, H, rays_per_frame / t1 / 1e6, fr, cores, fp, cores),
             "row_chunk_schedule": {"mrays_per_s": round(rate_r, 3), "ms_per_frame": round(elr / fr * 1e3, 3)},

@@ -90,8 +90,10 @@ def main():
     ap.add_argument("--size", default="", help="diagnostic only: WxH instead of the tag's own resolution (no golden z check then)")
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning: ray-list length below which stage 2 is cooperative (0 = library default)")
     ap.add_argument("--gather-float4", action="store_true",
-                    help="N>1: gather the float4 {r,g,b,z} shards (16 B per pixel) instead of the packed RenderImage content "
-                         "(float z + Color24, 7 B per pixel, converted on the device)")
+                    help="N>1: gather the float4 {r,g,b,z} shards (16 B per pixel) instead of the output images")
+    ap.add_argument("--gather-render-image", action="store_true",
+                    help="N>1: gather float z + Color24 (7 B per pixel, the reference's RenderImage arrays) instead of the two output images "
+                         "(Color24 + z-image byte, 4 B per pixel — the default: at these frame rates the link to the root is the bottleneck)")
     ap.add_argument("--allgather", action="store_true", help="N>1: all_gather the framebuffer to every rank instead of gathering it to rank 0")
     ap.add_argument("--dbg", type=int, default=0, help="experiment switches (rtu_debug_flags): the images are WRONG with anything but 0")
     ap.add_argument("--rehearse", action="store_true",
@@ -165,14 +167,18 @@ def main():
     # two shard / gather buffers: the RCCL gather of batch i runs while batch i+1 is rendered
     shards = [torch.zeros(B * max_rows * W * 4, dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     root_only = not args.allgather
-    # N > 1: what travels to the root is the reference's RenderImage content — float z + Color24, 7 bytes per pixel,
-    # converted on the device (rtu_pack_image_device) — unless --gather-float4 asks for the raw float4 shards
-    packed = world > 1 and not args.gather_float4
-    pbytes = sharding.packed_bytes(B, max_rows, W)
-    sends = [torch.zeros(pbytes, dtype=torch.uint8, device=dev) for _ in range(2)] if packed else shards
+    # N > 1: what travels to the root are the two OUTPUT images — Color24 + the z-image byte, 4 bytes per pixel, made on the device
+    # (rtu_minmax_z_device, one all-reduce MIN of the per-frame zmin / zmax keys, rtu_pack_output_device): at ~10 000 frames per
+    # second the root's xGMI links are the bottleneck, and Result.png / ZBuffer.png are what the reference writes.
+    # --gather-render-image: float z + Color24 (7 B per pixel, rtu_pack_image_device); --gather-float4: the raw float4 shards
+    out4 = world > 1 and not args.gather_float4 and not args.gather_render_image
+    packed = world > 1 and args.gather_render_image and not args.gather_float4
+    pbytes = sharding.out4_bytes(B, max_rows, W) if out4 else sharding.packed_bytes(B, max_rows, W)
+    sends = [torch.zeros(pbytes, dtype=torch.uint8, device=dev) for _ in range(2)] if (packed or out4) else shards
+    minmax = [torch.zeros(2 * B, dtype=torch.int64, device=dev) for _ in range(2)] if out4 else None
     gathers = None
     if world > 1 and (rank == 0 or not root_only):
-        if packed:
+        if packed or out4:
             gathers = [torch.empty(world, pbytes, dtype=torch.uint8, device=cdev) for _ in range(2)]
         else:
             gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
@@ -208,8 +214,35 @@ def main():
 
     pipe = sharding.FramePipeline(sends, gathers, dist, staged=args.rehearse, root_only=root_only) if dist else None
 
+    pending = [None]          # out4: the batch whose pack + gather are still to be queued (done after the NEXT batch's kernels are)
+    mmwork = [None, None]
+
+    def finish():
+        """out4: quantise and gather the batch rendered one step ago — by now its zmin / zmax all-reduce has long finished, so the
+        stream never idles waiting for it."""
+        if pending[0] is None:
+            return
+        i, nb = pending[0]
+        pending[0] = None
+        send = pipe.begin(i)  # waits (on the GPU) for the gather that last read this send buffer
+        if mmwork[i & 1] is not None:
+            mmwork[i & 1].wait()  # the current stream waits for the reduced keys (the host does not)
+        ctx.pack_output_device(shards[i & 1].data_ptr(), rows * W, nb, minmax[i & 1].data_ptr(), send.data_ptr(), stream)
+        pipe.gather(i)  # RCCL over xGMI, asynchronous
+
     def step(i, nb, ev=None):
         """One launch sequence: nb frames (steps) in flight."""
+        if out4:
+            if ev:
+                ev[0].record()
+            launch(frames[:nb], shards[i & 1])
+            ctx.minmax_z_device(shards[i & 1].data_ptr(), rows * W, nb, minmax[i & 1].data_ptr(), stream)  # this shard's zmin / zmax keys per frame
+            mmwork[i & 1] = sharding.allreduce_minmax(minmax[i & 1], dist, staged=args.rehearse)          # -> the frames' (MIN over the ranks)
+            finish()                 # pack + gather of the PREVIOUS batch, queued behind this batch's kernels
+            pending[0] = (i, nb)
+            if ev:
+                ev[1].record()
+            return
         buf = pipe.begin(i) if pipe else shard  # waits (on the GPU) for the gather that last read this buffer
         if packed:
             send, buf = buf, shards[i & 1]
@@ -227,6 +260,7 @@ def main():
         """Warm up until no recursion level needs more frame records than provisioned (every rank repeats if any has to)."""
         for attempt in range(2 * 6 + 1):
             fn()
+            finish()
             if pipe:
                 pipe.drain()
             settled = 1
@@ -273,6 +307,7 @@ def main():
         if dominant and nb != batches[0]:
             ctx.probe_kernel(None)  # the probe averages full batches only (a host-side flag: nothing is queued)
         step(j, nb, events[j])
+    finish()
     if pipe:
         pipe.drain()  # every frame of the timed region rendered AND gathered
     torch.cuda.synchronize()
@@ -308,7 +343,9 @@ def main():
     img = None
     if dist:
         if rank == 0:
-            if packed:
+            if out4:
+                rgb8, zimg8 = sharding.assemble_gathered_out4(pkg, gathered.view(world, -1).cpu().numpy(), 0, scene.desc.camera, W, H, world)
+            elif packed:
                 zimg, rgb8 = sharding.assemble_gathered_packed(pkg, gathered.view(world, -1).cpu().numpy(), 0, B, scene.desc.camera, W, H, world, max_rows)
                 img = np.zeros((H, W, 4), np.float32)
                 img[..., 3] = zimg
@@ -320,6 +357,12 @@ def main():
         print("[rehearsal: %d ranks on one GPU through gloo — not a measurement]" % world, file=sys.stderr)
     import hashlib
     z_ok = img is not None and not sampled and hashlib.sha256(np.ascontiguousarray(img[..., 3]).tobytes()).hexdigest() == meta["sha256_z_f32"]
+    if out4 and rank == 0 and not sampled and meta.get("sha256_zbuffer_u8"):
+        # the gathered frame IS the two output images: ZBuffer.png's pixels must be the reference's bit for bit (its z-image is the
+        # integer quantisation of the float z, frame-wide zmin / zmax included), Result.png's within one level
+        gold = np.load(os.path.join(gdir, "golden.npz"))
+        z_ok = (hashlib.sha256(np.ascontiguousarray(zimg8).tobytes()).hexdigest() == meta["sha256_zbuffer_u8"]
+                and int(np.abs(rgb8.astype(np.int32) - gold["result_u8"].astype(np.int32)).max()) <= 1)
 
     # -- the single-frame configuration: one frame per launch sequence (what BeginRender() of one image costs) ----------
     single = None
@@ -378,7 +421,9 @@ def main():
                                   if len(set(rays_of)) > 1 or not (args.same_camera or sampled) else "the scene's camera for every frame",
                        "frame_latency_ms": round(kernel_ms, 4),
                        "single_frame": single,
-                       "sharding": ("interleaved 8-row bands, RCCL gather of the %s to rank 0, overlapped with the next batch" % ("RenderImage content (float z + Color24, 7 B per pixel, packed on the device)" if packed else "float4 framebuffer")) if world > 1 else "single GPU",
+                       "sharding": ("interleaved 8-row bands, RCCL gather of the %s to rank 0, overlapped with the next batch" % (
+                           "two output images (Color24 + z-image byte, 4 B per pixel, made on the device after one all-reduce of the frames' zmin / zmax)" if out4
+                           else "RenderImage arrays (float z + Color24, 7 B per pixel, packed on the device)" if packed else "float4 framebuffer")) if world > 1 else "single GPU",
                        "z_bit_exact_vs_reference_golden": bool(z_ok)},
             "roofline": roof,
         }

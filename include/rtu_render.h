@@ -155,6 +155,20 @@ int  rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n
  * library's pow rounds a value sitting on a byte boundary the other way: within the +-1 level bar.) */
 int  rtu_pack_image_device(RtuContext* ctx, const void* d_rgbz, size_t n_pixels, void* d_z, void* d_rgb8, void* hip_stream);
 
+/* The two OUTPUT images of a batch of rendered frames, 4 bytes per pixel {r, g, b of Color24, z-image byte}: what Result.png and
+ * ZBuffer.png are written from (main.cpp:59-61), and what a multi-GPU gather has to move when the frame rate makes the link to
+ * the root the bottleneck (10 000 frames per second x 14.5 MB of float z + Color24 exceed one xGMI link). The z-image needs the
+ * FRAME-wide zmin / zmax (ComputeZBufferImage, scene.h:590-612):
+ *   rtu_minmax_z_device   d_minmax[2 i], [2 i + 1] (int64 each) = order-preserving keys of zmin and of zmax of frame i over this
+ *                         shard's pixels (frame i at float4 offset i * pixels_per_frame), encoded so that the element-wise MINIMUM of
+ *                         the arrays of all shards is the frame's (one all-reduce MIN of 2 n_frames int64; a single GPU skips it);
+ *   rtu_pack_output_device quantises with those: byte = int((zmax - z) / (zmax - zmin) * 255) clamped, 0 for a miss, in binary32 with
+ *                         a correctly rounded division, exactly as the reference; colours as rtu_pack_image_device.
+ * Both asynchronous on hip_stream. */
+int  rtu_minmax_z_device(RtuContext* ctx, const void* d_rgbz, size_t pixels_per_frame, int n_frames, void* d_minmax, void* hip_stream);
+int  rtu_pack_output_device(RtuContext* ctx, const void* d_rgbz, size_t pixels_per_frame, int n_frames, const void* d_minmax, void* d_out4,
+                            void* hip_stream);
+
 /* Render into the context's own framebuffer and copy the shard to host memory
  * h_rgbz (rtu_shard_rows * width * 4 floats). Synchronous. stats may be NULL. */
 int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz, RtuStats* stats);

@@ -141,7 +141,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
@@ -157,6 +157,8 @@ _sig(hip, "rtu_shard_global_row", _I, ctypes.POINTER(RtuFrameDesc), _I)
 _sig(hip, "rtu_render_frame_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, _P)
 _sig(hip, "rtu_render_frames_device", _I, _P, ctypes.POINTER(RtuFrameDesc), _I, _P, _P)
 _sig(hip, "rtu_pack_image_device", _I, _P, _P, ctypes.c_size_t, _P, _P, _P)
+_sig(hip, "rtu_minmax_z_device", _I, _P, _P, ctypes.c_size_t, _I, _P, _P)
+_sig(hip, "rtu_pack_output_device", _I, _P, _P, ctypes.c_size_t, _I, _P, _P, _P)
 _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuStats))
 _sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_get_touched", _I, _P, ctypes.POINTER(RtuTouched), _I)
@@ -332,6 +334,14 @@ class Context:
     def pack_image_device(self, d_rgbz, n_pixels, d_z, d_rgb8, stream=None):
         """float4 image -> float z + Color24 pixels (the reference's RenderImage content), on the device."""
         self._check(hip.rtu_pack_image_device(self._h, d_rgbz, n_pixels, d_z, d_rgb8, stream))
+
+    def minmax_z_device(self, d_rgbz, pixels_per_frame, n_frames, d_minmax, stream=None):
+        """Per frame of a batch: keys of this shard's zmin / zmax as int64 pairs (all-reduce MIN over the shards gives the frame's)."""
+        self._check(hip.rtu_minmax_z_device(self._h, d_rgbz, pixels_per_frame, n_frames, d_minmax, stream))
+
+    def pack_output_device(self, d_rgbz, pixels_per_frame, n_frames, d_minmax, d_out4, stream=None):
+        """float4 images -> 4 bytes per pixel {Color24, z-image byte}: the content of Result.png and ZBuffer.png."""
+        self._check(hip.rtu_pack_output_device(self._h, d_rgbz, pixels_per_frame, n_frames, d_minmax, d_out4, stream))
 
     def frame_status(self):
         """Synchronise; raises RtuError(RTU_ERR_CAPACITY) if the frame must be rendered again."""

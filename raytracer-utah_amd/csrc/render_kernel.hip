@@ -142,6 +142,75 @@ __global__ void __launch_bounds__(256) k_pack_image(const float4* rgbz, unsigned
 }
 }  // namespace
 
+// ---- the two OUTPUT images of a frame, 4 bytes per pixel: Color24 + the z-image byte of ComputeZBufferImage (scene.h:590-612) ----
+// The z-image needs the frame-wide zmin / zmax over the pixels that hit (z != BIGFLOAT). k_minmax_z reduces them per frame of a
+// batch into order-preserving integer keys (min as key, max as ~key, so that ONE element-wise MIN over the shards of all GPUs
+// combines both); k_pack_output then quantises with the reference's float expression (correctly rounded division, truncation).
+namespace {
+__device__ __forceinline__ uint32_t z_key(float z) {  // monotone: a < b  <=>  z_key(a) < z_key(b), all finite floats
+    const uint32_t b = __float_as_uint(z);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float z_unkey(uint32_t k) { return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ void __launch_bounds__(256) k_minmax_z(const float4* rgbz, uint32_t pixels_per_frame, long long* minmax) {
+    const uint32_t frame = blockIdx.y;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // nothing hit yet: zmin = BIGFLOAT, zmax = 0 are applied when the keys are read
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < pixels_per_frame; i += gridDim.x * 256u) {
+        const float z = rgbz[(size_t)frame * pixels_per_frame + i].w;
+        if (z == RTU_BIGFLOAT || z != z) continue;  // a miss; a NaN never wins a comparison in the reference's loop either
+        const uint32_t k = z_key(z);
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)kmin, off), b = (uint32_t)__shfl_xor((int)kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (kmin != 0xFFFFFFFFu) atomicMin((unsigned long long*)&minmax[2 * frame], (unsigned long long)kmin);
+        if (kmax != 0u) atomicMin((unsigned long long*)&minmax[2 * frame + 1], (unsigned long long)(~kmax));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack_output(const float4* rgbz, uint32_t pixels_per_frame, const long long* minmax, uchar4* out) {
+    const uint32_t frame = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pixels_per_frame) return;
+    // scene.h:596-601: float zmin = BIGFLOAT, zmax = 0, then min / max over the pixels that hit
+    const unsigned long long kmin = (unsigned long long)minmax[2 * frame], nkmax = (unsigned long long)minmax[2 * frame + 1];
+    float zmin = kmin > 0xFFFFFFFFull ? RTU_BIGFLOAT : z_unkey((uint32_t)kmin);
+    float zmax = nkmax > 0xFFFFFFFFull ? 0.0f : z_unkey(~(uint32_t)nkmax);
+    if (!(RTU_BIGFLOAT > zmin)) zmin = RTU_BIGFLOAT;  // `if (zmin > z) zmin = z` starting from BIGFLOAT: never above it
+    if (!(0.0f < zmax)) zmax = 0.0f;                  // `if (zmax < z) zmax = z` starting from 0: never below it
+    const float4 v = rgbz[(size_t)frame * pixels_per_frame + i];
+    uchar4 o;
+    o.x = float_to_byte((float)pow((double)v.x, 1 / 2.2));
+    o.y = float_to_byte((float)pow((double)v.y, 1 / 2.2));
+    o.z = float_to_byte((float)pow((double)v.z, 1 / 2.2));
+    o.w = v.w == RTU_BIGFLOAT ? (uint8_t)0 : float_to_byte((zmax - v.w) / (zmax - zmin));  // :603-609 (float_to_byte = int(f * 255), clamped)
+    out[(size_t)frame * pixels_per_frame + i] = o;
+}
+}  // namespace
+
+int rtu_launch_minmax_z(const float4* rgbz, uint32_t pixels_per_frame, uint32_t frames, long long* minmax, hipStream_t stream) {
+    if (pixels_per_frame == 0 || frames == 0) return (int)hipSuccess;
+    hipError_t e = hipMemsetAsync(minmax, 0x7F, sizeof(long long) * 2 * frames, stream);  // "nothing yet": any key is below 0x7F7F...
+    if (e != hipSuccess) return (int)e;
+    uint32_t bx = (pixels_per_frame + 255u) / 256u;
+    if (bx > 1024u) bx = 1024u;
+    hipLaunchKernelGGL(k_minmax_z, dim3(bx, frames), dim3(256), 0, stream, rgbz, pixels_per_frame, minmax);
+    return (int)hipGetLastError();
+}
+
+int rtu_launch_pack_output(const float4* rgbz, uint32_t pixels_per_frame, uint32_t frames, const long long* minmax, unsigned char* out, hipStream_t stream) {
+    if (pixels_per_frame == 0 || frames == 0) return (int)hipSuccess;
+    hipLaunchKernelGGL(k_pack_output, dim3((pixels_per_frame + 255u) / 256u, frames), dim3(256), 0, stream, rgbz, pixels_per_frame, minmax, (uchar4*)out);
+    return (int)hipGetLastError();
+}
+
 int rtu_launch_pack_image(const float4* rgbz, unsigned long long pixels, float* z_out, unsigned char* rgb_out, hipStream_t stream) {
     if (pixels == 0) return (int)hipSuccess;
     hipLaunchKernelGGL(k_pack_image, dim3((unsigned)((pixels + 255u) / 256u)), dim3(256), 0, stream, rgbz, pixels, z_out, (uint8_t*)rgb_out);

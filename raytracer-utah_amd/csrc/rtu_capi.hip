@@ -1323,6 +1323,27 @@ int rtu_pack_image_device(RtuContext* ctx, const void* d_rgbz, size_t n_pixels, 
     return RTU_OK;
 }
 
+int rtu_minmax_z_device(RtuContext* ctx, const void* d_rgbz, size_t pixels_per_frame, int n_frames, void* d_minmax, void* hip_stream) {
+    if (!ctx || n_frames < 0 || pixels_per_frame > 0xFFFFFFFFull) return RTU_ERR_ARG;
+    if (pixels_per_frame == 0 || n_frames == 0) return RTU_OK;
+    if (!d_rgbz || !d_minmax) return fail(ctx, RTU_ERR_ARG, "NULL buffer");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = (hipError_t)rtu_launch_minmax_z((const float4*)d_rgbz, (uint32_t)pixels_per_frame, (uint32_t)n_frames, (long long*)d_minmax, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
+int rtu_pack_output_device(RtuContext* ctx, const void* d_rgbz, size_t pixels_per_frame, int n_frames, const void* d_minmax, void* d_out4, void* hip_stream) {
+    if (!ctx || n_frames < 0 || pixels_per_frame > 0xFFFFFFFFull) return RTU_ERR_ARG;
+    if (pixels_per_frame == 0 || n_frames == 0) return RTU_OK;
+    if (!d_rgbz || !d_minmax || !d_out4) return fail(ctx, RTU_ERR_ARG, "NULL buffer");
+    RTU_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = (hipError_t)rtu_launch_pack_output((const float4*)d_rgbz, (uint32_t)pixels_per_frame, (uint32_t)n_frames, (const long long*)d_minmax,
+                                                      (unsigned char*)d_out4, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return RTU_OK;
+}
+
 int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     if (!ctx || !stats) return RTU_ERR_ARG;
     RTU_HIP(ctx, hipSetDevice(ctx->device));

@@ -264,6 +264,10 @@ int rtu_launch_resolve(const float4* acc, const uint32_t* hits, float4* out, uin
 // gamma + Color24 + z of a float4 image: the content of the reference's RenderImage
 int rtu_launch_pack_image(const float4* rgbz, unsigned long long pixels, float* z_out, unsigned char* rgb_out, hipStream_t stream);
 
+// the two output images of a batch of frames, 4 bytes per pixel (Color24 + z-image byte), and the per-frame zmin / zmax keys they need
+int rtu_launch_minmax_z(const float4* rgbz, uint32_t pixels_per_frame, uint32_t frames, long long* minmax, hipStream_t stream);
+int rtu_launch_pack_output(const float4* rgbz, uint32_t pixels_per_frame, uint32_t frames, const long long* minmax, unsigned char* out, hipStream_t stream);
+
 int rtu_launch_selftest_prims(unsigned long long n_rays, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 int rtu_launch_selftest_fdiv(unsigned long long n_pairs, unsigned long long seed, unsigned long long* d_mismatches, hipStream_t stream);
 

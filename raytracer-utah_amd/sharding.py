@@ -109,3 +109,37 @@ def global_minmax_z(z_local, dist, torch):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     return float(lo), float(hi)
+
+
+def out4_bytes(B, max_rows, width):
+    """Bytes of one rank's gather buffer for B frames in flight of output images (Color24 + z-image byte: 4 per pixel)."""
+    return B * max_rows * width * 4
+
+
+def assemble_gathered_out4(pkg, chunks_u8, j, camera, width, height, world):
+    """The default multi-GPU gather moves the two OUTPUT images, 4 bytes per pixel {r, g, b, z-image byte}
+    (rtu_pack_output_device): rank r's chunk (uint8) holds its shard of frame j at byte offset j * rows_r * W * 4.
+    Returns frame j as (rgb8 [H, W, 3] uint8 = the pixels of Result.png, zimg [H, W] uint8 = those of ZBuffer.png)."""
+    import numpy as np
+    rgb = np.empty((height, width, 3), np.uint8)
+    zimg = np.empty((height, width), np.uint8)
+    for r in range(world):
+        fr = pkg.frame_setup(camera, width, height, shard_rank=r, shard_count=world)
+        rows = pkg.shard_global_rows(fr)
+        n = len(rows) * width * 4
+        px = np.ascontiguousarray(chunks_u8[r])[j * n:(j + 1) * n].reshape(len(rows), width, 4)
+        rgb[rows] = px[..., :3]
+        zimg[rows] = px[..., 3]
+    return rgb, zimg
+
+
+def allreduce_minmax(mm, dist, staged=False):
+    """Element-wise MIN over the ranks of the int64 zmin / zmax keys of rtu_minmax_z_device (the max is stored complemented), in
+    place, asynchronously: returns the work handle (wait() makes the current stream wait, not the host). staged (rehearsal on
+    gloo): through a host copy, synchronously."""
+    if staged:
+        h = mm.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        mm.copy_(h)
+        return None
+    return dist.all_reduce(mm, op=dist.ReduceOp.MIN, async_op=True)

@@ -128,3 +128,35 @@ def test_sharded_gather_reassembles_the_frame(pkg, orc, golden, tmp_path, world)
         fj = np.load(tmp_path / ("batch%d.npy" % j))
         assert np.array_equal(fj, ref + np.float32(1000.0 if j == 1 else 0.0)), "frame %d of the gathered batch" % j
         assert lo == z[z != np.float32(1e30)].min() and hi == z[z != np.float32(1e30)].max()
+
+
+def test_output_image_chunks_reassemble(tmp_path):
+    """sharding.assemble_gathered_out4 (the layout of the default multi-GPU gather: 4 bytes per pixel, frame j of rank r at byte
+    offset j * rows_r * W * 4) puts every band of every rank back where it belongs, for band counts that do not divide evenly."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    spec = __import__("importlib.util").util.spec_from_file_location("rtu_sharding", os.path.join(repo, "raytracer-utah_amd", "sharding.py"))
+    sharding = __import__("importlib.util").util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    scene = pkg.Scene.from_blob_file(os.path.join(repo, "tests", "golden", "teapot2_240x135", "scene.rtus.gz"))
+    W, H, B = 240, 135, 3
+    rng = np.random.default_rng(5)
+    images = rng.integers(0, 256, size=(B, H, W, 4), dtype=np.uint8)
+    for world in (1, 2, 3, 8, 24):
+        max_rows = pkg.hip.rtu_shard_max_rows(H, world)
+        assert sharding.out4_bytes(B, max_rows, W) == B * max_rows * W * 4
+        chunks = []
+        for r in range(world):
+            fr = pkg.frame_setup(scene.desc.camera, W, H, shard_rank=r, shard_count=world)
+            rows = pkg.shard_global_rows(fr)
+            chunk = np.zeros(sharding.out4_bytes(B, max_rows, W), np.uint8)
+            n = len(rows) * W * 4
+            for j in range(B):
+                chunk[j * n:(j + 1) * n] = images[j][rows].reshape(-1)
+            chunks.append(chunk)
+        for j in range(B):
+            rgb, zimg = sharding.assemble_gathered_out4(pkg, chunks, j, scene.desc.camera, W, H, world)
+            assert np.array_equal(rgb, images[j][..., :3]) and np.array_equal(zimg, images[j][..., 3])

@@ -917,3 +917,49 @@ def test_tail_hint_from_another_view_is_refused_not_trusted(pkg, ctx, golden):
         assert np.array_equal(img.view(np.uint32), out.view(np.uint32))
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p13_200x150", "p1_256"])
+def test_output_images_packed_on_the_device(pkg, ctx, golden, tag):
+    """What the multi-GPU gather moves by default: the two output images, 4 bytes per pixel {Color24, z-image byte}
+    (rtu_minmax_z_device -> element-wise MIN over the shards -> rtu_pack_output_device). The z-image byte must be the reference's
+    ZBuffer.png bit for bit — its zmin / zmax are frame-wide, so three shards reduce their keys as the ranks' all-reduce would —
+    and the colours Result.png's within one level; a batch of two frames (the second an empty view) keeps its frames apart."""
+    import torch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtu_sharding", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer-utah_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    away = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+    for k in range(3):
+        away.dir[k] = -away.dir[k]
+    for world in (1, 3):
+        chunks, mms, bufs, rows_of = [], [], [], []
+        for r in range(world):
+            frs = [pkg.frame_setup(c, W, H, shard_rank=r, shard_count=world) for c in (scene.desc.camera, away)]
+            rows = pkg.shard_rows(frs[0])
+            buf = torch.zeros(2 * rows * W * 4, dtype=torch.float32, device="cuda")
+            ctx.render_frames_device(frs, buf.data_ptr(), None)
+            ctx.frame_status()
+            mm = torch.zeros(4, dtype=torch.int64, device="cuda")
+            ctx.minmax_z_device(buf.data_ptr(), rows * W, 2, mm.data_ptr(), None)
+            torch.cuda.synchronize()
+            bufs.append(buf); mms.append(mm); rows_of.append(rows)
+        red = torch.stack(mms).min(dim=0).values  # what all_reduce(MIN) leaves on every rank
+        for r in range(world):
+            out = torch.zeros(2 * rows_of[r] * W * 4, dtype=torch.uint8, device="cuda")
+            ctx.pack_output_device(bufs[r].data_ptr(), rows_of[r] * W, 2, red.data_ptr(), out.data_ptr(), None)
+            torch.cuda.synchronize()
+            chunks.append(out.cpu().numpy())
+        rgb, zimg = sharding.assemble_gathered_out4(pkg, chunks, 0, scene.desc.camera, W, H, world)
+        assert np.array_equal(zimg, g.npz["zbuffer_u8"]), "z-image differs from the reference's ZBuffer.png (%d shards)" % world
+        assert np.abs(rgb.astype(np.int32) - g.npz["result_u8"].astype(np.int32)).max() <= RGB8_TOL
+        rgb2, zimg2 = sharding.assemble_gathered_out4(pkg, chunks, 1, scene.desc.camera, W, H, world)
+        ref2, _ = ctx.render(pkg.frame_setup(away, W, H))
+        import __graft_entry__ as ge
+        c8, _, cz8 = ge.load_oracle().postprocess(ref2)
+        assert np.array_equal(zimg2, cz8) and np.abs(rgb2.astype(np.int32) - c8.astype(np.int32)).max() <= RGB8_TOL

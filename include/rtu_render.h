@@ -139,13 +139,13 @@ int  rtu_shard_global_row(const RtuFrameDesc* frame, int local_row);
  * HBM; nothing is copied. */
 int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream);
 
-/* Frames in flight: n_frames frames of recipe W of the uploaded scene — the same resolution, shard and
+/* Frames in flight: n_frames (<= RTU_MAX_FRAMES_IN_FLIGHT, and at most 2^26 pixels together) frames of recipe W of the uploaded scene — the same resolution, shard and
  * options, each with its own camera (cam_pos / origin / u / v) — rendered by ONE launch sequence into
  * d_rgbz = n_frames consecutive shard images (frame i at float4 offset i * rtu_shard_rows * width).
  * One 1080p frame at one sample per pixel is too little work to fill 256 CUs: sixteen in
  * flight render at 2.4 times the rays per second. Every frame is the image rtu_render_frame_device
  * gives for it, bit for bit. Asynchronous; rtu_frame_status afterwards as for a single frame. */
-#define RTU_MAX_FRAMES_IN_FLIGHT 32
+#define RTU_MAX_FRAMES_IN_FLIGHT 128
 int  rtu_render_frames_device(RtuContext* ctx, const RtuFrameDesc* frames, int n_frames, void* d_rgbz, void* hip_stream);
 
 /* The content of the reference's RenderImage from a rendered float4 image, on the device: d_z[i] = z,

@@ -341,7 +341,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     f3 cam_origin = ld3(a.frame.origin), cam_u = ld3(a.frame.u), cam_v = ld3(a.frame.v);
     ray.p = ld3(a.frame.cam_pos);
     if (BATD) {  // every frame of the batch has its own camera
-        const BatchCam& c = a.cam[sidx];
+        const RTU_CONST BatchCam& c = as_const(a.cam)[sidx];  // scalar loads where sidx is wave-uniform (stage 1)
         ray.p = ld3(c.pos);
         cam_origin = ld3(c.origin);
         cam_u = ld3(c.u);

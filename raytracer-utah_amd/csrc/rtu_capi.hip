@@ -71,6 +71,14 @@ struct RtuContext {
     hipEvent_t probe_ev[2 * kProbePairs] = {};
     struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
     std::vector<MeshInfo> mesh_info;
+    // cameras of a batch of frames: written into the next slot of a ring of pinned host slots, copied to d_cams on the launch
+    // stream ahead of the kernels (stream order protects d_cams; an event per slot protects the slot from being rewritten
+    // while its copy is still pending)
+    static const int kCamSlots = 16;
+    BatchCam* d_cams = nullptr;
+    BatchCam* h_cams = nullptr;
+    hipEvent_t cam_ev[kCamSlots] = {};
+    int cam_slot = 0;
     uint32_t dbg = 0;
     int4* node_rects = nullptr;              // [RTU_MAX_FRAME_BATCH][n_nodes] screen rectangles of the node-level bounds (k_node_rects); owned by the scene
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
@@ -765,12 +773,24 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         a.batch = (uint32_t)batch;
         a.batch_pixels = pixels;
         a.tiles_per_image = tiles_x * bands;
-        for (int b = 0; b < batch; b++) {
-            memcpy(a.cam[b].pos, frames_batch[b].cam_pos, sizeof a.cam[b].pos);
-            memcpy(a.cam[b].origin, frames_batch[b].origin, sizeof a.cam[b].origin);
-            memcpy(a.cam[b].u, frames_batch[b].u, sizeof a.cam[b].u);
-            memcpy(a.cam[b].v, frames_batch[b].v, sizeof a.cam[b].v);
+        if (!ctx->d_cams) {
+            RTU_HIP(ctx, hipMalloc((void**)&ctx->d_cams, sizeof(BatchCam) * RTU_MAX_FRAME_BATCH));
+            RTU_HIP(ctx, hipHostMalloc((void**)&ctx->h_cams, sizeof(BatchCam) * RTU_MAX_FRAME_BATCH * RtuContext::kCamSlots, hipHostMallocDefault));
+            for (hipEvent_t& e : ctx->cam_ev) RTU_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+        const int slot = ctx->cam_slot;
+        ctx->cam_slot = (slot + 1) % RtuContext::kCamSlots;
+        RTU_HIP(ctx, hipEventSynchronize(ctx->cam_ev[slot]));  // the copy that last read this slot (16 launches ago) is done; a fresh event is "done"
+        BatchCam* hc = ctx->h_cams + (size_t)slot * RTU_MAX_FRAME_BATCH;
+        for (int b = 0; b < batch; b++) {
+            memcpy(hc[b].pos, frames_batch[b].cam_pos, sizeof hc[b].pos);
+            memcpy(hc[b].origin, frames_batch[b].origin, sizeof hc[b].origin);
+            memcpy(hc[b].u, frames_batch[b].u, sizeof hc[b].u);
+            memcpy(hc[b].v, frames_batch[b].v, sizeof hc[b].v);
+        }
+        RTU_HIP(ctx, hipMemcpyAsync(ctx->d_cams, hc, sizeof(BatchCam) * (size_t)batch, hipMemcpyHostToDevice, stream));
+        RTU_HIP(ctx, hipEventRecord(ctx->cam_ev[slot], stream));
+        a.cam = ctx->d_cams;
     }
     if (gi) {
         a.gi_h = ctx->gi_h;
@@ -991,6 +1011,10 @@ void rtu_destroy_context(RtuContext* ctx) {
     free_levels(ctx);
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
     if (ctx->tl) (void)hipFree(ctx->tl);
+    if (ctx->d_cams) (void)hipFree(ctx->d_cams);
+    if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
+    for (hipEvent_t e : ctx->cam_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->acc) (void)hipFree(ctx->acc);
     if (ctx->acc_hits) (void)hipFree(ctx->acc_hits);

@@ -116,7 +116,7 @@ struct DevScene {
 // reference's exact term order.
 #define RTU_MAX_LEVELS        (RTU_MAX_BOUNCE + 1)
 #define RTU_MAX_BATCH 16          // samples of recipe S rendered by one launch sequence
-#define RTU_MAX_FRAME_BATCH 32    // frames of recipe W rendered by one launch sequence (== RTU_MAX_FRAMES_IN_FLIGHT)
+#define RTU_MAX_FRAME_BATCH 128   // frames of recipe W rendered by one launch sequence (== RTU_MAX_FRAMES_IN_FLIGHT)
 #define RTU_MAX_SHADOW_LIGHTS 13  // non-ambient lights (a ray id keeps 4 bits for lights + 3 secondary slots); more => RTU_ERR_UNSUPPORTED
 
 // frame info word (fa.w)
@@ -235,7 +235,7 @@ struct KernelArgs {
     uint32_t     gi_depth, gi_total;
     // a batch of FRAMES of recipe W (rtu_render_frames_device): the same index space, one camera per frame
     uint32_t     frame_batch;       // 0: no
-    BatchCam     cam[RTU_MAX_FRAME_BATCH];
+    const BatchCam* cam;            // [batch] in device memory (copied there on the launch stream, ahead of the kernels)
 };
 
 // Enqueue one frame (primary pass, then per level: trace, consume; then combine

@@ -632,14 +632,17 @@ def test_frames_in_flight_equal_single_frames(pkg, ctx, golden, tag, shards):
         pkg.hip.rtu_device_free(ctx._h, d)
     # errors: frames that differ in more than their cameras, too many frames, sampled frames
     a, b = pkg.frame_setup(scene.desc.camera, W, H), pkg.frame_setup(scene.desc.camera, W, H + 8)
-    d = pkg.hip.rtu_device_alloc(ctx._h, 36 * (H + 8) * W * 16)
+    d = pkg.hip.rtu_device_alloc(ctx._h, 128 * (H + 8) * W * 16)
     arr = (pkg.RtuFrameDesc * 2)(a, b)
     assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG
-    arr33 = (pkg.RtuFrameDesc * 33)(*([a] * 33))
-    assert pkg.hip.rtu_render_frames_device(ctx._h, arr33, 33, d, None) == pkg.RTU_ERR_ARG
-    arr32 = (pkg.RtuFrameDesc * 32)(*([a] * 32))
-    assert pkg.hip.rtu_render_frames_device(ctx._h, arr32, 32, d, None) == 0
+    arr129 = (pkg.RtuFrameDesc * 129)(*([a] * 129))  # RTU_MAX_FRAMES_IN_FLIGHT is 128
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr129, 129, d, None) == pkg.RTU_ERR_ARG
+    arr128 = (pkg.RtuFrameDesc * 128)(*([a] * 128))
+    assert pkg.hip.rtu_render_frames_device(ctx._h, arr128, 128, d, None) == 0
     ctx.frame_status()
+    last = np.empty((H, W, 4), np.float32)
+    assert pkg.hip.rtu_copy_to_host(ctx._h, last.ctypes.data, d + 127 * H * W * 16, last.nbytes) == 0
+    assert sha256(last[..., 3]) == g.meta["sha256_z_f32"] or shards != 1  # the 128th frame of the batch is the golden frame too
     s = pkg.frame_setup(scene.desc.camera, W, H, samples=2)
     arr = (pkg.RtuFrameDesc * 2)(s, s)
     assert pkg.hip.rtu_render_frames_device(ctx._h, arr, 2, d, None) == pkg.RTU_ERR_ARG

@@ -364,6 +364,17 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             const int x0 = rc[4u * k], y0 = rc[4u * k + 1u], x1 = rc[4u * k + 2u], y1 = rc[4u * k + 3u];
             if (x < x0 || x >= x1 || y < y0 || y >= y1) skip |= 1ull << k;
         }
+        if (a.cover) {  // inside a mesh's rectangle: does any of its triangles reach this 8x8 tile? (k_mesh_cover)
+            const uint32_t tile = (uint32_t)(y >> 3) * a.tiles_xf + (uint32_t)(x >> 3);
+            for (uint32_t c = 0; c < s.n_cover; c++) {
+                const uint32_t k = (uint32_t)s.cover_node[c];
+                const bool inside = valid && k < 64u && !((skip >> k) & 1ull);  // inside the mesh's rectangle
+                if (!__any(inside)) continue;                                    // (most wavefronts: no load at all)
+                const RTU_CONST uint32_t* m = as_const(a.cover) + ((size_t)sidx * s.n_cover + c) * (1u + a.cover_words);
+                if (inside && m[0] == 0u && !((m[1u + (tile >> 5)] >> (tile & 31u)) & 1u)) skip |= 1ull << k;
+            }
+            if (CNTD && leader && valid) cnt.t_bytes += 8u * s.n_cover;
+        }
         if (CNTD && leader && valid) cnt.t_bytes += 16u * nn;
         if (s.n_nodes <= 64u && __all(!valid || (skip & s.obj_mask) == s.obj_mask)) {
             if (valid && leader) {
@@ -1296,6 +1307,74 @@ __global__ void __launch_bounds__(64) k_node_rects(KernelArgs a, uint32_t entrie
     }
 }
 
+// COVERAGE MASKS (KernelArgs::cover): one thread per triangle of a mesh node, per camera of the launch. The triangle's own bounding
+// box in world space (its vertices through the node's chain of transformations, computed once at upload), widened by the cull margin
+// for this camera, is projected like the node bound in k_node_rects; every 8x8 tile its pixel rectangle (two pixels of slack) touches
+// gets its bit. A primary ray that hits the triangle has its hit point in that box, so its pixel is in a marked tile.
+__global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entries) {
+    const uint32_t e = blockIdx.y / a.scene.n_cover, c = blockIdx.y % a.scene.n_cover;
+    if (e >= entries) return;
+    uint32_t* m = a.cover + ((size_t)e * a.scene.n_cover + c) * (1u + a.cover_words);
+    // the 256 triangles of a workgroup mark a copy of the mask in LDS; its non-zero words are then added to the mask in memory
+    // (device-scope atomics are served one after the other per cache line: 6320 triangles x 6 tiles straight into 32 lines took 45 us)
+    extern __shared__ uint32_t s_mask[];
+    for (uint32_t i = threadIdx.x; i < a.cover_words; i += 256u) s_mask[i] = 0u;
+    __syncthreads();
+    const uint32_t face = blockIdx.x * 256u + threadIdx.x;
+    bool unusable = false;
+    if (face < a.scene.cover_nf[c]) {
+    // binary32 throughout: its rounding (1e-6 of the coordinates, a few thousandths of a pixel) is far inside the two pixels of slack
+    const float* cp = a.frame_batch ? a.cam[e].pos : a.frame.cam_pos;
+    const float* co = a.frame_batch ? a.cam[e].origin : a.frame.origin;
+    const float* cu = a.frame_batch ? a.cam[e].u : a.frame.u;
+    const float* cv = a.frame_batch ? a.cam[e].v : a.frame.v;
+    const f3 P = ld3(cp), U = ld3(cu), V = ld3(cv), O = ld3(co) - P;
+    // w = c (O + a U + b V): Cramer's rule on [U V O]; rows of the adjugate so that a corner costs three dot products
+    const f3 VxO = cross3(V, O), OxU = cross3(O, U), UxV = cross3(U, V);
+    const float det = dot3(U, VxO);
+    const float4 blo = a.scene.cover_box[c][2u * face], bhi = a.scene.cover_box[c][2u * face + 1u];  // the triangle's world-space box (upload)
+    const f3 lo = mk3(blo.x, blo.y, blo.z), hi = mk3(bhi.x, bhi.y, bhi.z);
+    const float pm = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
+    const float big = fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), fmaxf(fabsf(lo.z), fabsf(hi.z))));
+    const float wid = 1e-4f * fmaxf(a.scene.wscale, pm) + 1e-5f * big;  // the cull margin for this camera + the rounding of the chain
+    float amin = 3e38f, amax = -3e38f, bmin = 3e38f, bmax = -3e38f;
+    bool ok = det != 0.0f && wid == wid;
+    const float rdet = 1.0f / det;
+    for (int cn = 0; cn < 8 && ok; cn++) {
+        const f3 w = mk3(((cn & 1) ? hi.x + wid : lo.x - wid) - P.x, ((cn & 2) ? hi.y + wid : lo.y - wid) - P.y, ((cn & 4) ? hi.z + wid : lo.z - wid) - P.z);
+        const float da = dot3(w, VxO), db = dot3(w, OxU), dc = dot3(w, UxV);
+        if (!(dc * rdet > 1e-3f)) { ok = false; break; }  // at or behind the camera plane
+        const float rc = 1.0f / dc;
+        const float pa = da * rc, pb = db * rc;
+        amin = fminf(amin, pa); amax = fmaxf(amax, pa);
+        bmin = fminf(bmin, pb); bmax = fmaxf(bmax, pb);
+    }
+    const float W = (float)a.frame.width, H = (float)a.frame.height;
+    if (!ok || amin != amin || bmin != bmin || amax != amax || bmax != bmax) {
+        unusable = true;  // at or behind the camera plane (or NaN): this mask decides nothing
+    } else if (amax + 1.5f >= 0.0f && bmax + 1.5f >= 0.0f && amin - 2.5f <= W && bmin - 2.5f <= H) {  // (else: off the image)
+        const int x0 = (int)fmaxf(floorf(amin - 2.5f), 0.0f), x1 = (int)fminf(ceilf(amax + 1.5f), W);  // pixel x lies on the ray through a = x + 0.5
+        const int y0 = (int)fmaxf(floorf(bmin - 2.5f), 0.0f), y1 = (int)fminf(ceilf(bmax + 1.5f), H);
+        if (x1 > x0 && y1 > y0) {
+            const int tx0 = x0 >> 3, tx1 = (x1 - 1) >> 3, ty0 = y0 >> 3, ty1 = (y1 - 1) >> 3;
+            if ((long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4096) unusable = true;  // a triangle as large as the image: no mask for this mesh
+            else
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) {
+                        const uint32_t tile = (uint32_t)ty * a.tiles_xf + (uint32_t)tx;
+                        atomicOr(&s_mask[tile >> 5], 1u << (tile & 31u));
+                    }
+        }
+    }
+    }
+    if (unusable) m[0] = 1u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.cover_words; i += 256u) {
+        const uint32_t v = s_mask[i];
+        if (v) atomicOr(&m[1u + i], v);
+    }
+}
+
 // One kernel of the sequence; `slot` is its timeline / counter-table slot. With a probe on that slot the launch is
 // bracketed by HIP events on the launch stream (bench.py: the dominant kernel's duration inside the timed region).
 #define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
@@ -1328,6 +1407,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
+        if (!SMPD && a.cover) hipLaunchKernelGGL(k_mesh_cover, dim3((a.cover_faces + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_cover), dim3(256), a.cover_words * sizeof(uint32_t), stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);

@@ -80,6 +80,9 @@ struct RtuContext {
     hipEvent_t cam_ev[kCamSlots] = {};
     int cam_slot = 0;
     uint32_t dbg = 0;
+    uint32_t* cover = nullptr;               // coverage masks of primary rays (KernelArgs::cover), grown on demand
+    size_t    cover_cap = 0;                 // in words
+    uint32_t  cover_faces = 0;
     int4* node_rects = nullptr;              // [RTU_MAX_FRAME_BATCH][n_nodes] screen rectangles of the node-level bounds (k_node_rects); owned by the scene
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
     bool stamp_next = false;
@@ -741,6 +744,22 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.scene.dbg = ctx->dbg;
     a.counters = stats ? ctx->counters : nullptr;
     a.node_rects = (stats != 1 && frame->samples == 0 && ctx->dscene.node_bounds) ? ctx->node_rects : nullptr;
+    if (a.node_rects && ctx->dscene.n_cover && !gi && ((size_t)((frame->width + 7) / 8) * (size_t)((frame->height + 7) / 8) + 31u) / 32u <= 12288u) {  // (the mask has to fit k_mesh_cover's LDS copy)
+        a.tiles_xf = (uint32_t)((frame->width + 7) / 8);
+        a.cover_words = (a.tiles_xf * (uint32_t)((frame->height + 7) / 8) + 31u) / 32u;
+        a.cover_faces = ctx->cover_faces;
+        const size_t need = (size_t)batch * ctx->dscene.n_cover * (1u + a.cover_words);
+        if (need > ctx->cover_cap) {
+            RTU_HIP(ctx, hipStreamSynchronize(stream));  // (first launch at this size only) nothing may still read the old masks
+            if (ctx->cover) (void)hipFree(ctx->cover);
+            ctx->cover = nullptr;
+            ctx->cover_cap = 0;
+            RTU_HIP(ctx, hipMalloc((void**)&ctx->cover, need * sizeof(uint32_t)));
+            ctx->cover_cap = need;
+        }
+        RTU_HIP(ctx, hipMemsetAsync(ctx->cover, 0, need * sizeof(uint32_t), stream));
+        a.cover = ctx->cover;
+    }
     a.tiles_x = tiles_x;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
@@ -1011,6 +1030,7 @@ void rtu_destroy_context(RtuContext* ctx) {
     free_levels(ctx);
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
     if (ctx->tl) (void)hipFree(ctx->tl);
+    if (ctx->cover) (void)hipFree(ctx->cover);
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
     for (hipEvent_t e : ctx->cam_ev)
@@ -1203,6 +1223,35 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     for (uint32_t i = 0; i < s->n_lights; i++)
         for (int k = 0; k < 3; k++)
             if (!(std::fabs(s->lights[i].intensity[k]) < 1e15f)) ds.nol_ok = 0;
+    ds.n_cover = 0;
+    ctx->cover_faces = 0;
+    for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++) {
+        if (s->nodes[i].obj_type == RTU_OBJ_TRIMESH && ds.n_cover < RTU_MAX_COVER) {
+            ds.cover_node[ds.n_cover++] = (int32_t)i;
+            const RtuMesh& m = s->meshes[s->nodes[i].mesh_id];
+            if (m.nf > ctx->cover_faces) ctx->cover_faces = m.nf;
+            // world-space box of every triangle: vertices through the chain p -> tm p + pos in binary64, rounded outwards
+            std::vector<float4> boxes((size_t)m.nf * 2);
+            for (uint32_t f = 0; f < m.nf; f++) {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (int v = 0; v < 3; v++) {
+                    const float* lp = m.v + 3 * (size_t)m.f[3 * (size_t)f + v];
+                    double p[3] = {lp[0], lp[1], lp[2]};
+                    for (int j = (int)i; j >= 0; j = s->nodes[j].parent) {
+                        const RtuNode& t = s->nodes[j];
+                        const double q[3] = {p[0] * t.tm[0] + p[1] * t.tm[3] + p[2] * t.tm[6] + t.pos[0], p[0] * t.tm[1] + p[1] * t.tm[4] + p[2] * t.tm[7] + t.pos[1],
+                                             p[0] * t.tm[2] + p[1] * t.tm[5] + p[2] * t.tm[8] + t.pos[2]};
+                        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+                    }
+                    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+                }
+                boxes[2 * (size_t)f] = make_float4(std::nextafter((float)lo[0], -INFINITY), std::nextafter((float)lo[1], -INFINITY), std::nextafter((float)lo[2], -INFINITY), 0.0f);
+                boxes[2 * (size_t)f + 1] = make_float4(std::nextafter((float)hi[0], INFINITY), std::nextafter((float)hi[1], INFINITY), std::nextafter((float)hi[2], INFINITY), 0.0f);
+            }
+            if ((rc = upload(ctx, boxes.data(), boxes.size(), &ds.cover_box[ds.n_cover - 1])) != RTU_OK) return rc;
+            ds.cover_nf[ds.n_cover - 1] = m.nf;
+        }
+    }
     ds.obj_mask = 0;
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
         if (s->nodes[i].obj_type != RTU_OBJ_NONE) ds.obj_mask |= 1ull << i;

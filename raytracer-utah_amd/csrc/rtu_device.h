@@ -99,7 +99,10 @@ struct DevScene {
     uint32_t walk_stack_limit;  // test hook (rtu_debug_walk_stack_limit): stack entries the walks of the fast trees may use
     float    wscale;            // largest |coordinate| of any node-level bound: the scale of the cull margin in world space
     unsigned long long obj_mask;  // bit k: node k (< 64) carries an object
-    uint32_t nol_ok, pad_nol;   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
+    uint32_t nol_ok, n_cover;   // n_cover: mesh nodes with a coverage mask (the first RTU_MAX_COVER of them)
+    int32_t  cover_node[8];     // their node indices
+    const float4* cover_box[8]; // per masked mesh node: the WORLD-space box of every triangle, 2 float4 {lo, -} {hi, -} (computed at upload in
+    uint32_t cover_nf[8];       //   binary64, rounded outwards), and the triangle count   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
     uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg
     uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background
@@ -171,6 +174,7 @@ struct LevelBuffers {
 #define RTU_REF8_EMPTY   0x0FFFFFFFu
 #define RTU_LDS_NODE_F4  ((RTU_LDS_BYTES - RTU_COOP_GROUPS * RTU_STACK8 * 4) / 16)
 
+#define RTU_MAX_COVER 8       // mesh nodes that get a coverage mask for primary rays
 #define RTU_SHARDS 64
 #define RTU_TAIL_LEARN   256u   // the host hands levels to k_tail when the cut level held at most this many frames last time
 #define RTU_TAIL_DECLINE 4096u  // ... and k_tail refuses a cut level with more than this many (the hint was for another view)
@@ -211,6 +215,13 @@ struct KernelArgs {
     uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
     uint32_t     defer_cap_s;
     uint32_t     dbg;               // experiment switches (rtu_debug_flags); 0 in production
+    // COVERAGE MASKS of primary rays (recipe W): per camera of the launch and mesh node, one bit per 8x8-pixel tile of the image:
+    // can a primary ray through a pixel of the tile touch ANY triangle of the mesh? (k_mesh_cover: every triangle's world box, widened by
+    // the cull margin, projected like the node bound, two pixels of slack.) cover[(entry * n_cover + slot) * (1 + cover_words)]: word 0 = 1 if
+    // the mask is unusable (a triangle at or behind the camera plane, or one that covers thousands of tiles), then the bits.
+    uint32_t*    cover;
+    uint32_t     cover_words, tiles_xf;   // words of one mask; 8x8 tiles per row of the WHOLE image
+    uint32_t     cover_faces, pad_cf;     // the largest triangle count among the masked meshes (grid of k_mesh_cover)
     int4*        node_rects;        // recipe W: [batch entry][node] {x0, y0, x1, y1}: the pixels (global x, y; x0 <= x < x1) whose primary ray can
                                     // touch the node's bound from that entry's camera (k_node_rects); nullptr: not in use
     unsigned long long* counters;   // 11 x u64 (RtuStats order); touched-bytes mode: [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]; or nullptr

@@ -966,3 +966,50 @@ def test_output_images_packed_on_the_device(pkg, ctx, golden, tag):
         import __graft_entry__ as ge
         c8, _, cz8 = ge.load_oracle().postprocess(ref2)
         assert np.array_equal(zimg2, cz8) and np.abs(rgb2.astype(np.int32) - c8.astype(np.int32)).max() <= RGB8_TOL
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p7_200x150", "mtl_160x120"])
+def test_coverage_masks_with_the_camera_among_the_triangles(pkg, ctx, golden, tag):
+    """The coverage masks of primary rays (k_mesh_cover: one bit per 8x8 tile and mesh — can a primary ray there touch any
+    triangle?) from cameras where they are hardest: far away (the whole mesh in a few tiles), close up, INSIDE the mesh's
+    bounding box and looking along its surface (triangles at and behind the camera plane: the mask must declare itself unusable),
+    as frames in flight. Fast variant with the bounds and masks on == off == counting variant, bit for bit."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    m = ctypes.cast(scene.desc.meshes, ctypes.POINTER(pkg.RtuMesh))[0]
+    base = scene.desc.camera
+    cams = []
+    for k, (scale, fov) in enumerate([(6.0, 20.0), (0.45, 75.0), (0.12, 100.0), (0.02, 120.0), (1.0, 170.0)]):
+        cam = type(base).from_buffer_copy(base)
+        # towards / past the point the camera looks at: pos + dir * distance (scenes are built around the origin)
+        dist = sum(-base.pos[i] * base.dir[i] for i in range(3))
+        for i in range(3):
+            cam.pos[i] = base.pos[i] + base.dir[i] * dist * (1.0 - scale)
+        cam.fov = fov
+        cams.append(cam)
+    d = pkg.hip.rtu_device_alloc(ctx._h, len(cams) * W * H * 16)
+    results = {}
+    for on in (1, 0):
+        pkg.hip.rtu_debug_node_bounds(ctx._h, on)
+        frames = [pkg.frame_setup(c, W, H) for c in cams]
+        ctx.render_frames_device(frames, d, None)
+        for _ in range(8):
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError:
+                ctx.render_frames_device(frames, d, None)
+        out = np.empty((len(cams), H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+        results[on] = out
+    pkg.hip.rtu_debug_node_bounds(ctx._h, 1)
+    pkg.hip.rtu_device_free(ctx._h, d)
+    assert np.array_equal(results[1].view(np.uint32), results[0].view(np.uint32)), "bounds / coverage masks changed an image"
+    for i, c in enumerate(cams):
+        cnt, _ = ctx.render(pkg.frame_setup(c, W, H, collect_stats=True), stats=True)
+        assert np.array_equal(cnt.view(np.uint32), results[1][i].view(np.uint32)), "camera %d: fast and counting variants differ" % i
+        single, _ = ctx.render(pkg.frame_setup(c, W, H))
+        assert np.array_equal(single.view(np.uint32), results[1][i].view(np.uint32))
+    assert sum(bool((results[1][i][..., 3] < 1e29).any()) for i in range(len(cams))) >= 2, "the views show nothing"

@@ -244,7 +244,10 @@ int  rtu_get_stats(RtuContext* ctx, RtuStats* stats);
  *   + 112 inner4 (7 float4 of a 4-wide node) + 256 inner8 (8 x 32 B child records) + 64 inner_ref (a sibling pair of the reference's
  *   tree: exact-tie / stack-overflow fallback) + 64 tri_tests (triangle record) + 100 winners (element, face and normal indices, three
  *   vertices, three normals; 148 with texture vertices) + record_bytes (frame records, lists, shadow results, pixels: counted at
- *   every load / store). SURVEY 8d's per-unit figures with the record sizes of THIS layout in place of the reference's. */
+ *   every load / store). SURVEY 8d's per-unit figures with the record sizes of THIS layout in place of the reference's.
+ * Wave-uniform data — scene nodes and their bounds, mesh headers, screen rectangles — is read through the constant address space
+ * by scalar loads, ONCE PER WAVEFRONT whatever the number of lanes that need it: bound_tests, node_tests and mesh_box_tests count
+ * wavefronts, not lanes (the reference reads them once per ray; a GPU lane does not). Everything else is per lane. */
 #define RTU_KERNEL_SLOTS 40
 typedef struct RtuTouched {
     uint64_t rays;            /* Trace / ShadowTrace walks started by this launch */

@@ -323,7 +323,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     g.sum = sum;
     // enough wavefronts to fill 256 CUs several times over before widening them
     // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
-    g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 120000) ? 64u : 8u;
+    g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 70000) ? 64u : 8u;  // (round 2: the lists are shorter — masks — and so is the break-even: 40 / 70 / 100 / 120 k measured)
     g.kmax = (v + g.R - 1u) / g.R;
     return g;
 }
@@ -373,9 +373,9 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
                 const RTU_CONST uint32_t* m = as_const(a.cover) + ((size_t)sidx * s.n_cover + c) * (1u + a.cover_words);
                 if (inside && m[0] == 0u && !((m[1u + (tile >> 5)] >> (tile & 31u)) & 1u)) skip |= 1ull << k;
             }
-            if (CNTD && leader && valid) cnt.t_bytes += 8u * s.n_cover;
+            if (CNTD && leader && valid) cnt.t_bytes += 4u * s.n_cover;  // (the lane's word of each mask it looked at, at most)
         }
-        if (CNTD && leader && valid) cnt.t_bytes += 16u * nn;
+        if (CNTD && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.t_bytes += 16u * nn;  // wave-uniform: once per wavefront
         if (s.n_nodes <= 64u && __all(!valid || (skip & s.obj_mask) == s.obj_mask)) {
             if (valid && leader) {
                 RTU_CNT(prim);
@@ -585,6 +585,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     r.p = p;
     float tmax = RTU_BIGFLOAT;
     const bool is_shadow = slot < a.nsl;
+    int lslot = -1;  // shadow rays aimed at the light itself (not at a sample of its disk): which of the scene's shadow masks applies
     const int sslot = (int)slot - (int)a.nsl;
     if (is_shadow) {
         // ---- shadow ray (lightFunctions.cpp:27-37, 43-65, 75-78; lights.h:48)
@@ -593,9 +594,11 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         const int li = a.shadow_light[slot];
         const RTU_CONST RtuLight& l = as_const(s.lights)[li];
         f3 lvec = ld3(l.vec);
+        if (slot < RTU_LMASK_LIGHTS) lslot = (int)slot;
         if (l.type == RTU_LIGHT_DIRECT) {
             r.dir = -lvec;
         } else if (SMPD && l.size > 0) {
+            lslot = -1;
             // soft shadow: one ray towards a random point of the light's disk
             const Smp smp = frame_smp<TEX>(a, L, lv.fb[f].w);
             const float sampleR = (float)rand31(smp.key, RTU_DRAW_LIGHT + 2u * (uint32_t)li) / (RTU_RAND_MAX_F / l.size);  // :47
@@ -633,7 +636,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
     Hit h;
     fresh_hit(h, tmax);
     bool deferred;
-    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes);
+    const bool hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, r, is_shadow, h, stk, cnt, deferred, stride, lds_nodes, 0ull, false, lslot);
     if (DEFER && deferred) return true;
     if (!leader) return false;
     RTU_BYTES(is_shadow ? 4u : (TEXD ? 48u : 32u));

@@ -503,6 +503,104 @@ float world_bounds(const RtuSceneDesc* s, std::vector<DevNode>& nodes) {
     return (float)scale;
 }
 
+// SHADOW MASKS (DevLightMask): for each of the first RTU_LMASK_LIGHTS non-ambient lights and each masked mesh node, the mesh as
+// the light sees it. Every triangle's world-space box, widened by the cull margin (shadow rays start on the scene's surfaces:
+// |origin| <= the scene's scale), is projected corner by corner in binary64 — through a pinhole at a point light, looking at the
+// centre of the mesh; along the direction of a direct light — and the texels its rectangle touches (one texel of slack on every
+// side) are set. A mask is unusable when some corner is not in front of the pinhole (the light is inside or too close to the
+// mesh's hull) or the mesh has no extent from there. The frame, offset and scale go to the device as floats: their rounding
+// (1e-6 of the coordinates) is a few hundredths of a texel.
+int build_light_masks(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<std::vector<float4>>& tri_boxes, float wscale, DevScene& ds) {
+    ds.lmask = nullptr;
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < s->n_lights && lights.size() < RTU_LMASK_LIGHTS; i++)
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT) lights.push_back(i);
+    const uint32_t nc = (uint32_t)tri_boxes.size();
+    if (lights.empty() || nc == 0) return RTU_OK;
+    std::vector<DevLightMask> masks(lights.size() * nc);
+    memset(masks.data(), 0, masks.size() * sizeof(DevLightMask));
+    const double G = (double)RTU_LMASK_G;
+    for (size_t j = 0; j < lights.size(); j++) {
+        const RtuLight& l = s->lights[lights[j]];
+        const bool point = l.type == RTU_LIGHT_POINT;
+        for (uint32_t c = 0; c < nc; c++) {
+            DevLightMask& m = masks[j * nc + c];
+            const std::vector<float4>& boxes = tri_boxes[c];
+            const size_t nf = boxes.size() / 2;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (size_t f = 0; f < nf; f++) {
+                const float4 a = boxes[2 * f], b = boxes[2 * f + 1];
+                const double al[3] = {a.x, a.y, a.z}, bh[3] = {b.x, b.y, b.z};
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], al[k]); hi[k] = std::max(hi[k], bh[k]); }
+            }
+            double L[3] = {0, 0, 0}, Z[3];
+            if (point) {
+                for (int k = 0; k < 3; k++) { L[k] = l.vec[k]; Z[k] = 0.5 * (lo[k] + hi[k]) - L[k]; }
+            } else {
+                for (int k = 0; k < 3; k++) Z[k] = l.vec[k];
+            }
+            const double zl = std::sqrt(Z[0] * Z[0] + Z[1] * Z[1] + Z[2] * Z[2]);
+            if (!(zl > 0) || !std::isfinite(zl)) continue;  // unusable
+            for (int k = 0; k < 3; k++) Z[k] /= zl;
+            int ax = std::fabs(Z[0]) <= std::fabs(Z[1]) ? (std::fabs(Z[0]) <= std::fabs(Z[2]) ? 0 : 2) : (std::fabs(Z[1]) <= std::fabs(Z[2]) ? 1 : 2);
+            double A[3] = {0, 0, 0};
+            A[ax] = 1;
+            double X[3] = {Z[1] * A[2] - Z[2] * A[1], Z[2] * A[0] - Z[0] * A[2], Z[0] * A[1] - Z[1] * A[0]};
+            const double xl = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+            for (int k = 0; k < 3; k++) X[k] /= xl;
+            const double Y[3] = {Z[1] * X[2] - Z[2] * X[1], Z[2] * X[0] - Z[0] * X[2], Z[0] * X[1] - Z[1] * X[0]};
+            // per triangle: the rectangle of its widened box in the light's (u, v)
+            std::vector<double> rect(nf * 4);
+            double U0 = 1e300, U1 = -1e300, V0 = 1e300, V1 = -1e300;
+            bool ok = true;
+            for (size_t f = 0; f < nf && ok; f++) {
+                const float4 a = boxes[2 * f], b = boxes[2 * f + 1];
+                const double al[3] = {a.x, a.y, a.z}, bh[3] = {b.x, b.y, b.z};
+                double big = 0;
+                for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(al[k]), std::fabs(bh[k])));
+                const double wid = 1e-4 * (double)wscale + 1e-5 * big;
+                double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300;
+                for (int cn = 0; cn < 8; cn++) {
+                    const double q[3] = {((cn & 1) ? bh[0] + wid : al[0] - wid) - L[0], ((cn & 2) ? bh[1] + wid : al[1] - wid) - L[1],
+                                         ((cn & 4) ? bh[2] + wid : al[2] - wid) - L[2]};
+                    double u = q[0] * X[0] + q[1] * X[1] + q[2] * X[2], v = q[0] * Y[0] + q[1] * Y[1] + q[2] * Y[2];
+                    if (point) {
+                        const double depth = q[0] * Z[0] + q[1] * Z[1] + q[2] * Z[2];
+                        const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                        if (!(depth > 1e-3 * len)) { ok = false; break; }  // (within 89.94 degrees of the axis: tan stays below 1000)
+                        u /= depth; v /= depth;
+                    }
+                    u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
+                }
+                rect[4 * f] = u0; rect[4 * f + 1] = u1; rect[4 * f + 2] = v0; rect[4 * f + 3] = v1;
+                U0 = std::min(U0, u0); U1 = std::max(U1, u1); V0 = std::min(V0, v0); V1 = std::max(V1, v1);
+            }
+            if (!ok || !(U1 > U0) || !(V1 > V0)) continue;
+            const double mag = std::max(std::max(std::fabs(U0), std::fabs(U1)), std::max(std::fabs(V0), std::fabs(V1)));
+            if (!std::isfinite(mag) || (U1 - U0) < 1e-4 * mag || (V1 - V0) < 1e-4 * mag) continue;  // no extent a float lookup could resolve
+            // the grid spans the extent plus two texels on every side
+            const double du = (U1 - U0) / (G - 4), dv = (V1 - V0) / (G - 4);
+            const double gu0 = U0 - 2 * du, gv0 = V0 - 2 * dv;
+            for (size_t f = 0; f < nf; f++) {
+                int x0 = (int)std::floor((rect[4 * f] - gu0) / du) - 1, x1 = (int)std::floor((rect[4 * f + 1] - gu0) / du) + 1;
+                int y0 = (int)std::floor((rect[4 * f + 2] - gv0) / dv) - 1, y1 = (int)std::floor((rect[4 * f + 3] - gv0) / dv) + 1;
+                x0 = std::max(x0, 0); y0 = std::max(y0, 0);
+                x1 = std::min(x1, (int)RTU_LMASK_G - 1); y1 = std::min(y1, (int)RTU_LMASK_G - 1);
+                for (int y = y0; y <= y1; y++)
+                    for (int x = x0; x <= x1; x++) {
+                        const uint32_t t = (uint32_t)y * RTU_LMASK_G + (uint32_t)x;
+                        m.bits[t >> 5] |= 1u << (t & 31u);
+                    }
+            }
+            for (int k = 0; k < 3; k++) { m.X[k] = (float)X[k]; m.Y[k] = (float)Y[k]; m.Z[k] = (float)Z[k]; m.L[k] = (float)L[k]; }
+            m.u0 = (float)gu0; m.v0 = (float)gv0; m.su = (float)(1.0 / du); m.sv = (float)(1.0 / dv);
+            m.point = point ? 1u : 0u;
+            m.usable = 1u;
+        }
+    }
+    return upload(ctx, masks.data(), masks.size(), &ds.lmask);
+}
+
 // Reject anything the kernel's indexing does not expect, so that a malformed
 // scene is an error code and never an out-of-bounds access on the GPU.
 int validate(RtuContext* ctx, const RtuSceneDesc* s) {
@@ -1225,6 +1323,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             if (!(std::fabs(s->lights[i].intensity[k]) < 1e15f)) ds.nol_ok = 0;
     ds.n_cover = 0;
     ctx->cover_faces = 0;
+    std::vector<std::vector<float4>> cover_host;  // per masked mesh node: the world-space boxes of its triangles
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++) {
         if (s->nodes[i].obj_type == RTU_OBJ_TRIMESH && ds.n_cover < RTU_MAX_COVER) {
             ds.cover_node[ds.n_cover++] = (int32_t)i;
@@ -1250,8 +1349,10 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             }
             if ((rc = upload(ctx, boxes.data(), boxes.size(), &ds.cover_box[ds.n_cover - 1])) != RTU_OK) return rc;
             ds.cover_nf[ds.n_cover - 1] = m.nf;
+            cover_host.push_back(std::move(boxes));
         }
     }
+    if ((rc = build_light_masks(ctx, s, cover_host, wscale, ds)) != RTU_OK) return rc;
     ds.obj_mask = 0;
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
         if (s->nodes[i].obj_type != RTU_OBJ_NONE) ds.obj_mask |= 1ull << i;

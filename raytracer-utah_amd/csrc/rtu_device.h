@@ -77,6 +77,20 @@ struct DevNode {                // one scene-graph node (wave-uniform data)
     float   wmin[3], wmax[3];
 };
 
+// SHADOW MASK of one (non-ambient light, mesh node) pair, made at upload (rtu_capi.hip: build_light_masks): the mesh seen from the
+// light — a point light looks at it through a pinhole at its position, a direct light along its direction — as RTU_LMASK_G x
+// RTU_LMASK_G bits: can a ray between a surface point and the light touch ANY triangle of the mesh? A shadow ray's direction
+// from the light is fixed by its origin, so one lookup with the origin answers it (trace(): the mesh is skipped when the bit is
+// clear — conservative: every triangle's world box, widened by the cull margin, one texel of slack).
+#define RTU_LMASK_G 256u
+#define RTU_LMASK_LIGHTS 4u
+struct DevLightMask {
+    float X[3], Y[3], Z[3], L[3];   // the light's frame; L: its position (point light) or 0 (direct light: orthographic along Z)
+    float u0, v0, su, sv;           // texel = ((u - u0) * su, (v - v0) * sv)
+    uint32_t usable, point, pad[2];
+    uint32_t bits[RTU_LMASK_G * RTU_LMASK_G / 32u];
+};
+
 struct DevTexture {              // RtuTexture with the image in device memory
     int32_t type, width, height, pad;
     const uint8_t* rgb;
@@ -101,6 +115,7 @@ struct DevScene {
     unsigned long long obj_mask;  // bit k: node k (< 64) carries an object
     uint32_t nol_ok, n_cover;   // n_cover: mesh nodes with a coverage mask (the first RTU_MAX_COVER of them)
     int32_t  cover_node[8];     // their node indices
+    const DevLightMask* lmask;  // [min(non-ambient lights, RTU_LMASK_LIGHTS)][n_cover] shadow masks, or nullptr
     const float4* cover_box[8]; // per masked mesh node: the WORLD-space box of every triangle, 2 float4 {lo, -} {hi, -} (computed at upload in
     uint32_t cover_nf[8];       //   binary64, rounded outwards), and the triangle count   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
     uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg

@@ -46,6 +46,9 @@ struct Counters {
 // FC: the instantiation counts what it touches; `fc_lane`: this lane does the counting (one lane of the eight that share
 // a ray in the cooperative kernels)
 #define RTU_TOUCH(field, n) do { if (FC && fc_lane) cnt.field += (n); } while (0)
+// ... for WAVE-UNIFORM data (scene nodes, their bounds, mesh headers, screen rectangles: read through the constant address space by
+// scalar loads, once per wavefront whatever the number of lanes that need them): counted once per wavefront, by its first active lane
+#define RTU_TOUCH_WAVE(field, n) do { if (FC && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.field += (n); } while (0)
 
 // ---------------------------------------------------------------------------
 // Node::ToNodeCoords (scene.h:501-507): p' = itm*(p-pos); d' = itm*((p+d)-pos) - p'
@@ -928,7 +931,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
                                       const uint32_t stride = 64, const float4* lds_nodes = nullptr, const unsigned long long skip = 0,
-                                      const bool rays_bounded = false) {
+                                      const bool rays_bounded = false, const int lslot = -1) {
     const bool fc_lane = !COOP || (threadIdx.x & 7u) == 0;
     RTU_TOUCH(t_rays, 1);
     const bool bounds = CULL && s.node_bounds != 0 && !rays_bounded;  // wave-uniform
@@ -949,9 +952,39 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
         if (DEFER && deferred) continue;
         if (CULL && k < 64u && ((skip >> k) & 1ull)) continue;
+        if (CULL && lslot >= 0 && n.obj_type == RTU_OBJ_TRIMESH && s.lmask && s.node_bounds) {
+            // a shadow ray towards light `lslot` (lslot < RTU_LMASK_LIGHTS): the light's mask of this mesh, looked up with the ray's origin
+            int c = -1;
+            for (uint32_t i = 0; i < s.n_cover; i++) c = s.cover_node[i] == (int)k ? (int)i : c;
+            if (c >= 0) {
+                const RTU_CONST DevLightMask& m = as_const(s.lmask)[(uint32_t)lslot * s.n_cover + (uint32_t)c];
+                if (m.usable) {
+                    const f3 v = wr.p - ld3(m.L);
+                    float u = dot3(v, ld3(m.X)), w = dot3(v, ld3(m.Y));
+                    bool covered = true;
+                    if (m.point) {
+                        const float depth = dot3(v, ld3(m.Z));
+                        const float rd = __builtin_amdgcn_rcpf(depth);
+                        u *= rd; w *= rd;
+                        if (!(depth > 0.0f)) covered = false;  // the origin is on the far side of the light: the mesh is not between them
+                    }
+                    const float tu = (u - m.u0) * m.su, tw = (w - m.v0) * m.sv;
+                    if (covered) {
+                        if (!(tu >= 0.0f && tw >= 0.0f && tu < (float)RTU_LMASK_G && tw < (float)RTU_LMASK_G)) covered = tu != tu || tw != tw;  // outside the mesh's extent (NaN: no answer)
+                        else {
+                            const uint32_t texel = (uint32_t)tw * RTU_LMASK_G + (uint32_t)tu;
+                            covered = ((s.lmask[(uint32_t)lslot * s.n_cover + (uint32_t)c].bits[texel >> 5] >> (texel & 31u)) & 1u) != 0;
+                        }
+                    }
+                    RTU_TOUCH_WAVE(t_bytes, 64u);  // the mask's frame (scalar loads)
+                    RTU_TOUCH(t_bytes, 4u);        // ... and the lane's word of it
+                    if (!covered) continue;
+                }
+            }
+        }
         if (bounds) {
             float tn;
-            RTU_TOUCH(t_bounds, 1);
+            RTU_TOUCH_WAVE(t_bounds, 1);
             if (!fast_box(wf, make_float4(n.wmin[0], n.wmin[1], n.wmin[2], 0.0f), make_float4(n.wmax[0], n.wmax[1], n.wmax[2], 0.0f), h.z, tn)) continue;
         }
         int parent = n.parent;
@@ -970,8 +1003,8 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         }
         Ray lr = to_node(n, pr);
         RTU_CNT(node);
-        RTU_TOUCH(t_node, 1);
-        if (n.obj_type == RTU_OBJ_TRIMESH) RTU_TOUCH(t_meshbox, 1);
+        RTU_TOUCH_WAVE(t_node, 1);
+        if (n.obj_type == RTU_OBJ_TRIMESH) RTU_TOUCH_WAVE(t_meshbox, 1);
         bool hit;
         if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h, TEX);
         else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h, TEX);

@@ -1013,3 +1013,61 @@ def test_coverage_masks_with_the_camera_among_the_triangles(pkg, ctx, golden, ta
         single, _ = ctx.render(pkg.frame_setup(c, W, H))
         assert np.array_equal(single.view(np.uint32), results[1][i].view(np.uint32))
     assert sum(bool((results[1][i][..., 3] < 1e29).any()) for i in range(len(cams))) >= 2, "the views show nothing"
+
+
+def test_shadow_masks_with_lights_in_awkward_places(pkg, orc, tmp_path):
+    """The shadow masks (one per non-ambient light and mesh node, made at upload: the mesh as the light sees it; a shadow ray looks
+    its origin up) where they are hardest: a point light INSIDE the mesh's hull and one almost touching it (masks unusable), a point
+    light far away (the mesh in a corner of its own mask), direct lights along an axis and grazing the mesh's base, six
+    non-ambient lights (only the first four get masks), two mesh nodes of one mesh under different transformations. Masks and
+    bounds on == off == counting variant bit for bit, counters equal to the oracle's, images within the bars of the oracle."""
+    obj = tmp_path / "bumps.obj"
+    n = 10
+    import math
+    verts = [(i * 0.4 - 2.0, j * 0.4 - 2.0, 0.6 * math.sin(0.9 * i) * math.cos(0.7 * j)) for i in range(n + 1) for j in range(n + 1)]
+    vid = lambda i, j: i * (n + 1) + j + 1
+    faces = []
+    for i in range(n):
+        for j in range(n):
+            faces += [(vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)), (vid(i, j), vid(i + 1, j + 1), vid(i, j + 1))]
+    obj.write_text("".join("v %r %r %r\n" % v for v in verts) + "".join("f %d %d %d\n" % f for f in faces))
+    xml = tmp_path / "lights.xml"
+    xml.write_text("""<xml><scene>
+      <object type="obj" name="{o}" material="m"><scale value="1.2"/><translate x="-1" y="0" z="1"/></object>
+      <object name="grp"><rotate angle="40" z="1"/><translate x="3.5" y="1" z="0"/>
+        <object type="obj" name="{o}" material="shiny"><scale x="0.6" y="0.6" z="1.5"/><rotate angle="70" x="1"/><translate z="2"/></object></object>
+      <object type="plane" name="floor" material="m"><scale value="20"/></object>
+      <object type="sphere" name="ball" material="shiny"><scale value="0.8"/><translate x="0.5" y="-3" z="0.8"/></object>
+      <material type="blinn" name="m"><diffuse r="0.6" g="0.6" b="0.55"/><specular value="0.3"/><glossiness value="20"/></material>
+      <material type="blinn" name="shiny"><diffuse r="0.3" g="0.4" b="0.6"/><specular value="0.7"/><glossiness value="50"/><reflection value="0.4"/></material>
+      <light type="ambient" name="a"><intensity value="0.1"/></light>
+      <light type="point" name="inside"><intensity value="0.4"/><position x="-1" y="0" z="1.05"/></light>
+      <light type="direct" name="down"><intensity value="0.3"/><direction x="0" y="0" z="-1"/></light>
+      <light type="point" name="far"><intensity value="0.5"/><position x="40" y="-60" z="50"/></light>
+      <light type="direct" name="grazing"><intensity value="0.3"/><direction x="1" y="0.2" z="-0.02"/></light>
+      <light type="point" name="touching"><intensity value="0.2"/><position x="-1.0" y="0.4" z="1.73"/></light>
+      <light type="direct" name="sixth"><intensity value="0.2"/><direction x="-0.3" y="0.5" z="-1"/></light>
+    </scene><camera><position x="2" y="-11" z="6"/><target x="0.5" y="0" z="1"/><up x="0" y="0" z="1"/><fov value="45"/>
+      <width value="200"/><height value="150"/></camera></xml>""".format(o=obj))
+    scene = pkg.Scene.from_xml(str(xml))
+    assert scene.desc.n_meshes == 1 and scene.desc.n_lights == 7
+    W, H = 200, 150
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(scene)
+        cpu, cst = orc.render(scene, W, H, threads=8)
+        cnt, gst = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+        assert gst == cst
+        imgs = {}
+        for on in (1, 0):
+            pkg.hip.rtu_debug_node_bounds(ctx._h, on)
+            for coop in (1, 10 ** 9):
+                fr = pkg.frame_setup(scene.desc.camera, W, H, collect_stats=2)
+                fr.coop_threshold = coop
+                img, _ = ctx.render(fr)
+                assert np.array_equal(img.view(np.uint32), cnt.view(np.uint32)), "fast (bounds %d) and counting variants differ" % on
+            imgs[on] = sum(c["rays"] for k, c in ctx.touched().items() if k.startswith("k_trace2"))
+        assert imgs[1] < imgs[0], "the masks kept no shadow ray out of stage 2 (%d vs %d)" % (imgs[1], imgs[0])
+        check_against(img, cpu, orc)
+    finally:
+        ctx.close()

@@ -78,8 +78,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-bounce", type=int, default=5, help="diagnostic only: values other than 5 are not the workload")
     ap.add_argument("--frames-in-flight", type=int, default=-1,
-                    help="frames rendered by one launch sequence (rtu_render_frames_device). Default: as many as keep 2^25 pixels in "
-                         "flight on a GPU, at most 128 (16 full 1080p frames, 128 shards of an eighth of the frame). 1: one frame per launch "
+                    help="frames rendered by one launch sequence (rtu_render_frames_device). Default: as many as keep 2^26 pixels in "
+                         "flight on a GPU, at most 128 (32 full 1080p frames, 128 shards of a quarter of the frame or less). 1: one frame per launch "
                          "sequence — the frame LATENCY configuration")
     ap.add_argument("--same-camera", action="store_true", help="diagnostic only: every frame of a batch from the golden camera (no turntable)")
     ap.add_argument("--samples", type=int, default=0,
@@ -158,7 +158,7 @@ def main():
     if sampled:
         B = 1  # recipe S batches its samples itself
     elif B < 1:
-        B = max(1, min(128, (1 << 25) // max(1, max_rows * W)))
+        B = max(1, min(128, (1 << 26) // max(1, max_rows * W)))
     B = max(1, min(B, 128, args.steps))
     # the turntable: camera j of a batch (0: the scene's own camera, the one the golden z belongs to)
     cams = [orbit_camera(scene.desc.camera, 0.0 if (args.same_camera or sampled) else ORBIT_STEP_DEG * j) for j in range(B)]

@@ -755,7 +755,7 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     int rc;
     size_t total = 0;
     for (int L = 0; L < RTU_MAX_LEVELS; L++) total += want[L] * RTU_SHARDS * (size_t)(16 * 11 + 4 * (ctx->nsl ? ctx->nsl : 1) + 12);
-    if (total > ((size_t)96 << 30)) return fail(ctx, RTU_ERR_CAPACITY, "the recursion of this frame needs %zu GB of frame records", total >> 30);
+    if (total > ((size_t)160 << 30)) return fail(ctx, RTU_ERR_CAPACITY, "the recursion of this frame needs %zu GB of frame records", total >> 30);
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         LevelBuffers& lv = ctx->lv[L];
         size_t cap_s = want[L];

@@ -390,11 +390,13 @@ def main():
             tfile = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
             if world == 1 and args.tag == WORKLOAD_TAG and os.path.exists(tfile):
                 prof = json.load(open(tfile))
-            traffic = (prof.get("per_kernel", {}).get(kname) or {}).get("hbm_bytes_per_launch") if prof.get("frames_in_flight") == batches[0] else None
+            traffic = (prof.get("per_kernel", {}).get(kname) or {}).get("hbm_bytes_per_launch")
+            if traffic and prof.get("frames_in_flight") and prof["frames_in_flight"] != batches[0]:
+                traffic = int(traffic * batches[0] / prof["frames_in_flight"])  # profiled at another batch size: per frame in flight, times this run's
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic,
-                    "traffic_source": ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at %s, not measured in this run"
-                                       % prof.get("commit", "?")) if traffic else None,
+                    "traffic_source": ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py at commit %s with %s frames in flight "
+                                       "(scaled to this run's %d), not measured in this run" % (prof.get("commit", "?"), prof.get("frames_in_flight"), batches[0])) if traffic else None,
                     "kernel": kname, "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
                     "l2_peak": L2_PEAK_GBS, "l2_frac": round(achieved / L2_PEAK_GBS, 5),
                     "bytes_are": "touched by the timed (fast) kernels themselves, counted per kernel by collect_stats=2 (rtu_render.h RtuTouched)",

@@ -481,6 +481,22 @@ __global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, u
         const int y = (int)((band_local * a.frame.shard_count + a.frame.shard_rank) * RTU_BAND_ROWS + (lane >> 3));  // global row
         const bool valid = x < a.frame.width && y < a.frame.height;
         const uint32_t pix = ((SMPD || BATD) ? sidx * a.batch_pixels : 0u) + (uint32_t)ly * (uint32_t)a.frame.width + (uint32_t)x;
+        if (!STATS && !SMPD && !GID && a.occ != nullptr) {
+            // TILE OCCUPANCY (k_tile_occ): no pixel of this tile is inside any node's screen rectangle (or marked tile of a mesh's
+            // coverage mask) for this camera — most of a frame, typically: the background, and on to the next tile without a look
+            // at the camera, the rectangles or the masks (the same pixels primary_pixel's own test would send here)
+            const uint32_t w = as_const(a.occ)[(size_t)sidx * a.occ_words + (tile >> 5)];  // wave-uniform: a scalar load
+            if (!((w >> (tile & 31u)) & 1u)) {
+                if (valid) {
+                    const f3 bg = background_sample<TEXD>(a.scene, x, y);  // :145
+                    a.out[pix] = make_float4(bg.x, bg.y, bg.z, RTU_BIGFLOAT);
+                    RTU_BYTES(16u);
+                    if (CNTD) cnt.t_rays++;  // the ray exists; it touches nothing
+                }
+                if (CNTD && lane == 0) cnt.t_bytes += 4u;  // the occupancy word, once per wavefront
+                continue;
+            }
+        }
         const uint32_t shard = btile % RTU_SHARDS;
         bool deferred;
         primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
@@ -1378,6 +1394,44 @@ __global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entri
     }
 }
 
+// TILE OCCUPANCY (KernelArgs::occ): one thread per 8x8 tile of the shard, per camera of the launch: is any valid pixel of the tile
+// inside the screen rectangle of an object node (k_node_rects) and, where that node is a mesh with a usable coverage mask
+// (k_mesh_cover), in a tile the mask marks? Exactly the pixels primary_pixel's own rectangle / mask test would keep: a tile with
+// a zero bit is one whose wavefront would write the background for every pixel. Needs n_nodes <= 64 (the host checks).
+__global__ void __launch_bounds__(64) k_tile_occ(KernelArgs a, uint32_t entries) {
+    const uint32_t e = blockIdx.y;
+    if (e >= entries) return;
+    const DevScene& s = a.scene;
+    const uint32_t tiles = a.tiles_per_image;
+    const uint32_t tile = blockIdx.x * 64u + threadIdx.x;
+    bool occ = false;
+    if (tile < tiles) {
+        const uint32_t band_local = tile / a.tiles_x, tx = tile - band_local * a.tiles_x;
+        const int x0 = (int)(tx * 8u), y0 = (int)((band_local * (uint32_t)a.frame.shard_count + (uint32_t)a.frame.shard_rank) * RTU_BAND_ROWS);
+        const int x1 = x0 + 8 < a.frame.width ? x0 + 8 : a.frame.width, y1 = y0 + 8 < a.frame.height ? y0 + 8 : a.frame.height;
+        const uint32_t gtile = (uint32_t)(y0 >> 3) * a.tiles_xf + tx;
+        for (uint32_t k = 0; k < s.n_nodes && k < 64u; k++) {
+            if (!((s.obj_mask >> k) & 1ull)) continue;
+            const int4 r = a.node_rects[(size_t)e * s.n_nodes + k];
+            if (!(x0 < r.z && x1 > r.x && y0 < r.w && y1 > r.y)) continue;  // no pixel of the tile inside the rectangle
+            bool masked_out = false;
+            if (a.cover)
+                for (uint32_t c = 0; c < s.n_cover; c++)
+                    if ((uint32_t)s.cover_node[c] == k) {
+                        const uint32_t* m = a.cover + ((size_t)e * s.n_cover + c) * (1u + a.cover_words);
+                        if (m[0] == 0u && !((m[1u + (gtile >> 5)] >> (gtile & 31u)) & 1u)) masked_out = true;
+                    }
+            if (!masked_out) occ = true;
+        }
+    }
+    const unsigned long long bits = __ballot(occ);
+    if (threadIdx.x == 0) {
+        uint32_t* o = const_cast<uint32_t*>(a.occ) + (size_t)e * a.occ_words + 2u * blockIdx.x;
+        o[0] = (uint32_t)bits;
+        o[1] = (uint32_t)(bits >> 32);
+    }
+}
+
 // One kernel of the sequence; `slot` is its timeline / counter-table slot. With a probe on that slot the launch is
 // bracketed by HIP events on the launch stream (bench.py: the dominant kernel's duration inside the timed region).
 #define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
@@ -1411,6 +1465,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     } else {
         if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         if (!SMPD && a.cover) hipLaunchKernelGGL(k_mesh_cover, dim3((a.cover_faces + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_cover), dim3(256), a.cover_words * sizeof(uint32_t), stream, a, (BATD ? a.batch : 1u));
+        if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);

@@ -83,6 +83,8 @@ struct RtuContext {
     uint32_t* cover = nullptr;               // coverage masks of primary rays (KernelArgs::cover), grown on demand
     size_t    cover_cap = 0;                 // in words
     uint32_t  cover_faces = 0;
+    uint32_t* occ = nullptr;                 // tile occupancy of primary rays (KernelArgs::occ), grown on demand
+    size_t    occ_cap = 0;                   // in words
     int4* node_rects = nullptr;              // [RTU_MAX_FRAME_BATCH][n_nodes] screen rectangles of the node-level bounds (k_node_rects); owned by the scene
     unsigned long long* tl = nullptr;        // timeline stamps, RTU_TL_KERNELS x RTU_TL_STRIDE (rtu_render_timeline)
     bool stamp_next = false;
@@ -858,7 +860,21 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         RTU_HIP(ctx, hipMemsetAsync(ctx->cover, 0, need * sizeof(uint32_t), stream));
         a.cover = ctx->cover;
     }
+    if (a.node_rects && !gi && ctx->dscene.n_nodes <= 64u && stats != 1 && !(ctx->dbg & 256u)) {  // tile occupancy: every word is written by k_tile_occ on this launch
+        a.occ_words = ((tiles_x * bands + 63u) / 64u) * 2u;
+        const size_t need = (size_t)batch * a.occ_words;
+        if (need > ctx->occ_cap) {
+            RTU_HIP(ctx, hipStreamSynchronize(stream));  // (first launch at this size only) nothing may still read the old words
+            if (ctx->occ) (void)hipFree(ctx->occ);
+            ctx->occ = nullptr;
+            ctx->occ_cap = 0;
+            RTU_HIP(ctx, hipMalloc((void**)&ctx->occ, need * sizeof(uint32_t)));
+            ctx->occ_cap = need;
+        }
+        a.occ = ctx->occ;
+    }
     a.tiles_x = tiles_x;
+    a.tiles_per_image = tiles_x * bands;
     a.nsl = ctx->nsl;
     a.n_meshes = ctx->n_meshes;
     // the cut level for k_tail: what a launch of the same shape showed last time (a hint: any value renders the same image, a
@@ -1129,6 +1145,7 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
     if (ctx->tl) (void)hipFree(ctx->tl);
     if (ctx->cover) (void)hipFree(ctx->cover);
+    if (ctx->occ) (void)hipFree(ctx->occ);
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
     for (hipEvent_t e : ctx->cam_ev)

@@ -239,6 +239,12 @@ struct KernelArgs {
     uint32_t     cover_faces, pad_cf;     // the largest triangle count among the masked meshes (grid of k_mesh_cover)
     int4*        node_rects;        // recipe W: [batch entry][node] {x0, y0, x1, y1}: the pixels (global x, y; x0 <= x < x1) whose primary ray can
                                     // touch the node's bound from that entry's camera (k_node_rects); nullptr: not in use
+    // TILE OCCUPANCY (recipe W, fast variant): per camera of the launch one bit per 8x8 tile OF THE SHARD (tile = band * tiles_x + tx, the
+    // index k_primary strides over): 0 = no valid pixel of the tile lies inside any object node's screen rectangle — or, for a masked mesh
+    // node, in a tile its coverage mask marks —: k_primary writes the background without looking at cameras, rectangles or masks
+    // (k_tile_occ, from node_rects and cover). occ[entry * occ_words + (tile >> 5)]; nullptr: not in use
+    const uint32_t* occ;
+    uint32_t     occ_words, pad_occ;
     unsigned long long* counters;   // 11 x u64 (RtuStats order); touched-bytes mode: [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]; or nullptr
     uint32_t     tiles_x;           // ceil(width / 8)
     uint32_t     nsl;               // number of non-ambient lights

@@ -1071,3 +1071,40 @@ def test_shadow_masks_with_lights_in_awkward_places(pkg, orc, tmp_path):
         check_against(img, cpu, orc)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p11_240x135", "p4_240x135", "p7_200x150"])
+def test_tile_occupancy_changes_nothing_but_the_work(pkg, ctx, golden, tag):
+    """k_tile_occ: one bit per 8x8 tile of the shard and camera — can any pixel of it lie inside a node's screen rectangle (and a
+    marked tile of a mesh's coverage mask)? k_primary writes the background of the other tiles without a look at cameras,
+    rectangles or masks. Same bits with the shortcut on and off (rtu_debug_flags 256): ragged sizes (edge tiles, a 1x1 image),
+    three shards (the shard's own tile index against the image's), a batch of turned cameras; and the counting variant."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    try:
+        for (W, H) in [(g.width, g.height), (61, 45), (1, 1), (131, 77)]:
+            res = {}
+            for flag in (0, 256):
+                assert pkg.hip.rtu_debug_flags(ctx._h, flag) == 0
+                imgs = [render_gpu(pkg, ctx, scene, W, H, stats=False, shard_count=n)[0] for n in (1, 3)]
+                cams = []
+                for i in range(3):
+                    cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+                    cam.pos[0] += 2.1 * i
+                    cam.fov += 11.0 * i
+                    cams.append(cam)
+                d = pkg.hip.rtu_device_alloc(ctx._h, 3 * W * H * 16)
+                ctx.render_frames_device([pkg.frame_setup(c, W, H) for c in cams], d, None)
+                ctx.frame_status()
+                out = np.empty((3, H, W, 4), np.float32)
+                assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+                pkg.hip.rtu_device_free(ctx._h, d)
+                res[flag] = imgs + [out]
+            for a, b in zip(res[0], res[256]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "tile occupancy changed the image at %dx%d" % (W, H)
+            assert np.array_equal(res[0][0].view(np.uint32), res[0][1].view(np.uint32))
+            cnt, _ = render_gpu(pkg, ctx, scene, W, H, stats=True)
+            assert np.array_equal(res[0][0].view(np.uint32), cnt.view(np.uint32)), "fast and counting variants differ at %dx%d" % (W, H)
+    finally:
+        pkg.hip.rtu_debug_flags(ctx._h, 0)

@@ -66,7 +66,8 @@ namespace {
 #define RTU_OCC_TRACE
 #endif
 #ifndef RTU_OCC_WALK
-#define RTU_OCC_WALK
+// the one-lane-per-ray stage-2 walks: three wavefronts per SIMD (<= 168 VGPRs; k_primary2 left alone takes 173 and fits two)
+#define RTU_OCC_WALK __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 #ifndef RTU_OCC_CONSUME
 #define RTU_OCC_CONSUME

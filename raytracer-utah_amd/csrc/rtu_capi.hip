@@ -651,6 +651,8 @@ int validate(RtuContext* ctx, const RtuSceneDesc* s) {
             return fail(ctx, RTU_ERR_ARG, "mesh %u: missing array (normals are required, objects.h:56)", mi);
         if (m.n_bvh_nodes < 2 || m.n_elements != m.nf || m.nf == 0) return fail(ctx, RTU_ERR_ARG, "mesh %u: empty", mi);
         if (m.n_bvh_nodes >= (1u << 28) || m.n_elements >= (1u << 28)) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: more than 2^28 nodes/elements", mi);
+        // the fast walk addresses its triangle records (64 B) and 4-wide nodes (128 B, fewer than triangles) with 32-bit byte offsets
+        if (m.nf >= (1u << 26) || m.n_elements >= (1u << 26)) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: more than 2^26 triangles", mi);
         if (m.bvh_depth > RTU_MAX_BVH_STACK) return fail(ctx, RTU_ERR_UNSUPPORTED, "mesh %u: BVH depth %u > %d", mi, m.bvh_depth, RTU_MAX_BVH_STACK);
         for (uint32_t i = 0; i < m.nf * 3; i++) {
             if (m.f[i] >= m.nv) return fail(ctx, RTU_ERR_ARG, "mesh %u: vertex index out of range", mi);
@@ -958,7 +960,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 // After the stream has drained: did any recursion level run out of frame capacity?
 // Frames per level of the frame just finished -> where k_tail may take over in the next one.
 void learn_tail(RtuContext* ctx, const FrameCounters& h) {
-    const uint32_t kTailMax = RTU_TAIL_LEARN;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
+    static const uint32_t kTailEnv = [] { const char* e = getenv("RTU_TAIL_LEARN"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();  // tuning knob
+    const uint32_t kTailMax = kTailEnv ? kTailEnv : RTU_TAIL_LEARN;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
                                                // wavefront by wavefront are slower than their levels kernel by kernel
     uint32_t frames[RTU_MAX_LEVELS];
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {

@@ -28,6 +28,33 @@ template <class T> __device__ __forceinline__ const RTU_CONST T* as_const(const 
 #pragma clang diagnostic pop
 }
 
+// Per-lane gathers from the BVH / triangle arrays go through the GLOBAL address space with a wave-uniform base in scalar
+// registers and a 32-bit byte offset per lane. The pointers come out of a mesh header in memory, so the compiler cannot know
+// where they point and emits FLAT loads for plain dereferences: a 64-bit address per lane and load, one counter shared with
+// the LDS stack (every pop waits for the loads in flight and vice versa) — measured in the ISA of the round-2 walk.
+#define RTU_GLOBAL __attribute__((address_space(1)))
+typedef float rtu_v4f __attribute__((ext_vector_type(4)));
+struct GBase {
+    const RTU_GLOBAL char* p;
+};
+template <class T> __device__ __forceinline__ GBase global_base(const T* ptr) {  // ptr must be wave-uniform
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    GBase g;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    g.p = (const RTU_GLOBAL char*)(((unsigned long long)hi << 32) | lo);
+#pragma clang diagnostic pop
+    return g;
+}
+__device__ __forceinline__ float4 gload4(GBase g, uint32_t byte_off) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const rtu_v4f v = *(const RTU_GLOBAL rtu_v4f*)(g.p + byte_off);
+#pragma clang diagnostic pop
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // One BVH over a mesh's triangles with its leaf-ordered triangle records.
 struct DevTree {
     const float4*   bvh;        // 2 float4 per node: {bmin.xyz, index} {bmax.xyz, count}; root = node 1; breadth-first

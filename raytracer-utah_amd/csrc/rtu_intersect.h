@@ -624,20 +624,24 @@ __device__ __forceinline__ bool reaches_like_the_reference(const float* v, const
 // The fast variant's walk of the SAH tree: near child first (by the inflated entry distance —
 // the order only affects speed: an exact tie between two accepted triangles, the one case where
 // the order would show, is detected by tri_hit<TIE> and resolved on the reference's tree).
+__device__ __forceinline__ TriRec load_tri(GBase tri, uint32_t slot) {
+    TriRec t;
+    const uint32_t o = slot << 6;
+    t.r0 = gload4(tri, o); t.r1 = gload4(tri, o + 16u); t.r2 = gload4(tri, o + 32u); t.r3 = gload4(tri, o + 48u);
+    return t;
+}
 template <int STACK, bool FC = false, class MeshT>
 __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray, bool shadow, Hit& h, uint32_t* stk, Counters& cnt,
                                                const uint32_t stride, bool& tie, const uint32_t stackLimit) {
     const bool fc_lane = true;
     const int slim = (int)(stackLimit < (uint32_t)STACK ? stackLimit : (uint32_t)STACK);
-    // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches.
-    const float4* bvh4 = mesh.bvh4;
-    const float4* tris = mesh.fast.tri;
-    // (the mesh header is constant memory: left alone the compiler re-loads both pointers with a scalar load — and waits for it — in
-    // every step of the walk; pinned in vector registers they are loaded once)
-    asm volatile("" : "+v"(bvh4), "+v"(tris));
+    // The tree collapsed to four children per node (DevMesh::bvh4): half the dependent fetches. Bases in scalar registers,
+    // 32-bit byte offsets per lane, global loads (rtu_device.h GBase).
+    const GBase bvh4 = global_base(mesh.bvh4);
+    const GBase tris = global_base(mesh.fast.tri);
     const FastRay fr = fast_ray(ray, mesh.scale);
-    // near / far plane arrays of a node, by the sign of the ray (see build_wide4)
-    const uint32_t onx = fr.px ? 0u : 3u, ofx = 3u - onx, ony = fr.py ? 1u : 4u, ofy = 5u - ony, onz = fr.pz ? 2u : 5u, ofz = 7u - onz;
+    // near / far plane arrays of a node, by the sign of the ray (see build_wide4): byte offsets inside the 128-byte node
+    const uint32_t onx = fr.px ? 0u : 48u, ofx = 48u - onx, ony = fr.py ? 16u : 64u, ofy = 80u - ony, onz = fr.pz ? 32u : 80u, ofz = 112u - onz;
     bool hitResult = false;
     TriWin win;
     win.slot = 0;
@@ -648,8 +652,13 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
     while (alive) {
         while (alive && count == 0) {  // inner nodes
             RTU_TOUCH(t_inner4, 1);
-            const float4* nd = bvh4 + (size_t)index * 8u;
-            const float4 nx = nd[onx], ny = nd[ony], nz = nd[onz], fx = nd[ofx], fy = nd[ofy], fz = nd[ofz], rf = nd[6];
+            const uint32_t nb = index << 7;
+            const float4 nx = gload4(bvh4, nb + onx), ny = gload4(bvh4, nb + ony), nz = gload4(bvh4, nb + onz);
+            const float4 fx = gload4(bvh4, nb + ofx), fy = gload4(bvh4, nb + ofy), fz = gload4(bvh4, nb + ofz);
+            float4 rf = gload4(bvh4, nb + 96u);
+            // (the child references are needed only where a child is hit: left alone the compiler sinks their load below the box
+            // tests — a SECOND dependent round trip to memory in every step of the walk. Issued with the planes instead.)
+            asm volatile("" : "+v"(rf.x), "+v"(rf.y), "+v"(rf.z), "+v"(rf.w));
             const float inf = __builtin_inff();
 #define RTU_CHILD(c)                                                                                                       \
             const float tn##c = fmaxf(fmaxf(fmaf(nx.c, fr.r.x, fr.cn.x), fmaf(ny.c, fr.r.y, fr.cn.y)), fmaf(nz.c, fr.r.z, fr.cn.z)); \
@@ -689,16 +698,24 @@ __device__ __forceinline__ bool mesh_walk_fast(const MeshT& mesh, const Ray& ray
             index = next & 0x0FFFFFFFu;
             count = next >> 28;
         }
-        if (alive) {  // leaf; the next record is fetched while the current one is tested
+        if (alive) {
+            // leaf: its records are fetched one test ahead, in two buffers taking turns (a single "current / next" pair costs 26
+            // register moves per triangle: measured in the ISA of the round-2 walk)
             RTU_TOUCH(t_tri, count);
-            TriRec cur = load_tri(tris, index);
-            for (uint32_t i = 0; i < count; i++) {
-                TriRec nxt = cur;
-                if (i + 1 < count) nxt = load_tri(tris, index + i + 1);
-                const int code = tri_hit<false, true>(cur, index + i, ray, h, win, cnt);
+            TriRec A = load_tri(tris, index), B = A;
+            for (uint32_t i = 0;; i += 2u) {
+                const bool hasB = i + 1u < count;
+                if (hasB) B = load_tri(tris, index + i + 1u);
+                int code = tri_hit<false, true>(A, index + i, ray, h, win, cnt);
                 if (code == 2 && hitResult && !shadow) tie = true;  // equal t with the current best of THIS mesh
                 hitResult |= code == 1;
-                cur = nxt;
+                if (!hasB) break;
+                const bool hasA = i + 2u < count;
+                if (hasA) A = load_tri(tris, index + i + 2u);
+                code = tri_hit<false, true>(B, index + i + 1u, ray, h, win, cnt);
+                if (code == 2 && hitResult && !shadow) tie = true;
+                hitResult |= code == 1;
+                if (!hasA) break;
             }
             if (tie) alive = false;
             if (shadow && hitResult) {

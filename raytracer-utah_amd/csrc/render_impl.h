@@ -473,6 +473,8 @@ __global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, u
     // tiles are strided over the grid (a wavefront renders several: the launch has fewer, longer-lived wavefronts)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the tile arithmetic stays in scalar registers
     for (uint32_t btile = blockIdx.x * 4u + wave; btile < n_tiles; btile += gridDim.x * 4u) {  // whole wavefronts
+        // (two scalar divisions per tile; replacing them by additions and carries from a per-wavefront decomposition of the stride was
+        // measured: no faster — six more scalar registers in a kernel that already spills them)
         const uint32_t sidx = (SMPD || BATD) ? btile / a.tiles_per_image : 0u;  // batched launches: n_tiles = batch x tiles of the image
         const uint32_t tile = btile - sidx * a.tiles_per_image;
         const uint32_t band_local = tile / a.tiles_x;

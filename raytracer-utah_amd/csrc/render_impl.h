@@ -1456,6 +1456,20 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     // (round 2, counters on lines of their own: 32768 workgroups for k_trace(L0) 135 -> 125 us, 16384 for k_consume(L0) 134 -> 109 us;
     // 16384 or 65536 instead of 32768 for the one-lane-per-ray stage 2: +3 % / +1 %)
     const dim3 gridT(32768), gridN(32768), gridS(8192), gridF0(16384), gridF(4096), gridC(1024), gridCoop(512);
+    // (KernelArgs::list_n) the stage-2 kernel of a phase that is not expected to find work gets a grid that costs less to launch
+    // and still gets through the list should it be the one after all: cooperative up to the threshold (narrow_geom)
+    const uint32_t thr = (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 70000);
+    auto grid_lane = [&](int ph, dim3 full) {  // one lane per ray
+        const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
+        if (n1 == 0u || n1 - 1u > thr) return full;  // unknown, or this kernel's list
+        uint32_t g = ((n1 - 1u + 63u) / 64u) * 2u;
+        g = g < 256u ? 256u : g;
+        return g < full.x ? dim3(g) : full;
+    };
+    auto grid_coop = [&](int ph) {
+        const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
+        return (n1 != 0u && n1 - 1u > 2u * (uint64_t)thr) ? dim3(16) : gridCoop;
+    };
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
     const uint32_t blocksP = (n_tiles + 3) / 4;
@@ -1471,8 +1485,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
-            RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a);
-            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), gridN, block, a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);
         }
     }
     if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
@@ -1490,8 +1504,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L, (k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, a, L, sel, ph);
             if (a.n_meshes) {
-                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), gridCoop, dim3(RTU_COOP_THREADS), a, L, sel, ph);
-                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), L == 0 ? gridN : gridS, block, a, L, sel, ph);
+                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop(ph), dim3(RTU_COOP_THREADS), a, L, sel, ph);
+                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph);
             }
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);
         }

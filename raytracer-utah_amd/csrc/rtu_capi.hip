@@ -56,6 +56,7 @@ struct RtuContext {
     // any value renders the same image); last_tail_from: what the most recent frame was launched with
     int      tail_hint = 0, last_tail_from = RTU_MAX_LEVELS;   // tail_hint: set by rtu_debug_tail_from for the next launch (0: none)
     std::map<uint64_t, int> tail_hints;   // per launch shape (tiles of the launch, feature set): learned cut level
+    std::map<uint64_t, std::array<uint32_t, 8>> list_hints;  // ... and the rays deferred in every phase, + 1 (KernelArgs::list_n)
     uint64_t last_tail_key = 0;
     bool     last_stats = false;
     uint32_t n_meshes = 0;
@@ -888,6 +889,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     else if (ctx->tail_hints.count(tail_key)) hint = ctx->tail_hints[tail_key];
     a.tail_from = stats == 1 ? RTU_MAX_LEVELS : hint;
     ctx->last_tail_key = tail_key;
+    if (stats == 0 && !(ctx->dbg & 512u) && ctx->list_hints.count(tail_key)) memcpy(a.list_n, ctx->list_hints[tail_key].data(), sizeof a.list_n);
     if (forced) a.dbg |= 128u;  // a cut level set by the test hook is taken as it is (k_tail does not refuse it)
     if (frame->samples >= 1) {
         const float pixelIncrement = (float)(1.0 / frame->samples);  // RenderFunctions.cpp:68
@@ -975,6 +977,14 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
         if (frames[L] <= kTailMax) { hint = L; break; }
     // the launch had a tail and its cut level was not small after all: deeper counts are unknown, learn them from a launch without
     ctx->tail_hints[ctx->last_tail_key] = hint;
+    // the rays deferred in every phase (+ 1): what the next launch of this shape sizes its idle stage-2 kernels by
+    std::array<uint32_t, 8> lh{};
+    for (int p = 0; p <= RTU_MAX_LEVELS && p < 8; p++) {
+        uint64_t n = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) n += h.n_defer[p][(s) * RTU_CSTRIDE];
+        lh[p] = (uint32_t)(n < 0xFFFFFFF0ull ? n : 0xFFFFFFF0ull) + 1u;
+    }
+    ctx->list_hints[ctx->last_tail_key] = lh;
 }
 
 // The append counters keep counting past the capacity, so an overflowed frame tells how much its
@@ -1400,6 +1410,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ctx->want_defer_s = 0;
     ctx->tail_hint = 0;
     ctx->tail_hints.clear();
+    ctx->list_hints.clear();
     ctx->n_meshes = s->n_meshes;
     ctx->mesh_info = mesh_info;
     ctx->any_recursive_material = false;

@@ -279,6 +279,12 @@ struct KernelArgs {
     float        nol_light[RTU_FI_NOL_LIGHTS][4];      // the first non-ambient lights {vec.xyz, 1 = direct}: make_info tests N.L without a dependent load
     uint32_t     n_meshes;
     int32_t      tail_from;         // recursion levels >= this are evaluated by k_tail (RTU_MAX_LEVELS: none)
+    // HOST ONLY (launch_all): rays deferred in every tracing phase by the last launch of this shape, + 1 (0: unknown; phase 0 =
+    // primary rays, 1 + L = rays of level L). A phase has two stage-2 kernels of which one finds work (narrow_geom); an empty
+    // launch of 32768 workgroups costs 9 us, of 512 x 1024 threads 2.4 us (GPU-clock timeline of a single frame). The one that is
+    // expected to be idle gets a smaller grid: the one-lane-per-ray kernel one that would still get through twice the last
+    // list, the cooperative kernel a token one when the list was beyond twice the threshold. Any grid renders the same image.
+    uint32_t     list_n[8];
     // recipe S (frame.samples >= 1): one launch sequence per sample
     // `batch` consecutive samples at once, as [sample][pixel of the shard] (longer ray lists fill the chip better)
     uint32_t     sampling;          // 0: recipe W

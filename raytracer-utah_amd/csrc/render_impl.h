@@ -1463,7 +1463,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
         if (n1 == 0u || n1 - 1u > thr) return full;  // unknown, or this kernel's list
         uint32_t g = ((n1 - 1u + 63u) / 64u) * 2u;
-        g = g < 256u ? 256u : g;
+        g = g < 2048u ? 2048u : g;  // (two wavefronts per SIMD: a list ten times the last one is still walked at two thirds of the full rate)
         return g < full.x ? dim3(g) : full;
     };
     auto grid_coop = [&](int ph) {

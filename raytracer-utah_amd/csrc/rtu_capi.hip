@@ -889,7 +889,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     else if (ctx->tail_hints.count(tail_key)) hint = ctx->tail_hints[tail_key];
     a.tail_from = stats == 1 ? RTU_MAX_LEVELS : hint;
     ctx->last_tail_key = tail_key;
-    if (stats == 0 && !(ctx->dbg & 512u) && ctx->list_hints.count(tail_key)) memcpy(a.list_n, ctx->list_hints[tail_key].data(), sizeof a.list_n);
+    // (not for recipe P: its chain and shading launches share one shape and have lists of very different lengths)
+    if (stats == 0 && !gi && !(ctx->dbg & 512u) && ctx->list_hints.count(tail_key)) memcpy(a.list_n, ctx->list_hints[tail_key].data(), sizeof a.list_n);
     if (forced) a.dbg |= 128u;  // a cut level set by the test hook is taken as it is (k_tail does not refuse it)
     if (frame->samples >= 1) {
         const float pixelIncrement = (float)(1.0 / frame->samples);  // RenderFunctions.cpp:68

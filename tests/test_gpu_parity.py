@@ -1108,3 +1108,31 @@ def test_tile_occupancy_changes_nothing_but_the_work(pkg, ctx, golden, tag):
             assert np.array_equal(res[0][0].view(np.uint32), cnt.view(np.uint32)), "fast and counting variants differ at %dx%d" % (W, H)
     finally:
         pkg.hip.rtu_debug_flags(ctx._h, 0)
+
+
+def test_stage2_grids_from_the_last_launch_are_only_a_hint(pkg, ctx, golden):
+    """The stage-2 kernel of a phase that found no work last time is launched with a smaller grid (KernelArgs::list_n). A view far
+    from the mesh (short lists: the cooperative kernel's) followed by one close to it (long lists: the one-lane-per-ray
+    kernel's, now on the small grid) and back again (the cooperative kernel on its token grid): every image equals the counting
+    variant's, which takes no hints."""
+    g = golden("teapot2_240x135")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = 320, 200
+    far = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+    near = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+    for i in range(3):
+        far.pos[i] = scene.desc.camera.pos[i] * 3.0
+    near.fov = 12.0
+    near.dir[0], near.dir[1], near.dir[2] = 2.5 - near.pos[0], -8.0 - near.pos[1], 1.5 - near.pos[2]  # at the teapot
+    ref = {}
+    for name, cam in (("far", far), ("near", near)):
+        ref[name], _ = ctx.render(pkg.frame_setup(cam, W, H, collect_stats=True), stats=True)
+    counts = {}
+    for name, cam in (("far", far), ("near", near), ("far", far), ("near", near)):
+        fr = pkg.frame_setup(cam, W, H)
+        fr.coop_threshold = 600
+        img, _ = ctx.render(fr)  # (the synchronous entry reads the counters afterwards: the next launch of this shape takes its hints from them)
+        assert np.array_equal(img.view(np.uint32), ref[name].view(np.uint32)), "stale grid hints changed the %s view" % name
+        counts[name] = ctx.frame_counts()[1]
+    assert max(counts["far"]) < 600 and max(counts["near"]) > 1200, "the two views do not straddle the threshold: %s" % counts

@@ -214,7 +214,10 @@ int  rtu_debug_tail_from(RtuContext* ctx, int level);
 int  rtu_debug_node_bounds(RtuContext* ctx, int on);
 
 /* Experiment switches for performance work (which part of a kernel costs what): bits are defined next to their use in
- * render_impl.h; anything but 0 renders WRONG images. Never set in production paths or tests of results. */
+ * render_impl.h; bits 0..7 render WRONG images: never set them in production paths or tests of results. Two bits only switch an
+ * optimisation off and leave every result bit alone (tests compare the images with and without): 256 = no tile occupancy
+ * (k_primary tests every tile against the node rectangles and coverage masks itself), 512 = no stage-2 grid hints (both
+ * stage-2 kernels of every tracing phase are launched at full size). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on

@@ -132,6 +132,17 @@ __device__ __forceinline__ uint32_t shard_count(const KernelArgs& a, int L, uint
     return v > cap ? cap : v;
 }
 
+// The 64 shard populations of a list, one per lane (lane i: shard i), loaded ONCE per wavefront; a chunk reads its shard's with
+// v_readlane. (Every chunk of every kernel used to load its counter from memory first: one more dependent round trip in front
+// of the list entry, the frame record, the material — the chunk loops of the streaming kernels wait for memory half their time.)
+__device__ __forceinline__ uint32_t shard_counts(const uint32_t* counters, uint32_t cap) {
+    uint32_t v = counters[(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
+    return v > cap ? cap : v;
+}
+__device__ __forceinline__ uint32_t count_of(uint32_t counts, uint32_t shard) {  // shard: wave-uniform
+    return (uint32_t)__builtin_amdgcn_readlane((int)counts, (int)shard);
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counters& cnt) {
     if (!STATS) return;
@@ -532,10 +543,10 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
+    const uint32_t counts = shard_counts(a.fcnt->n_defer[0], a.defer_cap_s);
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][(shard) * RTU_CSTRIDE];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t ns = count_of(counts, shard);
         const uint32_t e = k * 64u + lane;
         const bool valid = e < ns;
         uint32_t pix = 0;
@@ -693,10 +704,12 @@ __global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L,
     const uint32_t chM = ((vm + 63u) / 64u) * RTU_SHARDS, chC = ((vc + 63u) / 64u) * RTU_SHARDS;
     const uint32_t total = a.nsl * chA + 2u * chM + chC;
     Counters cnt = {};
+    const uint32_t cntF = shard_counts(a.fcnt->n_frames[L], lv.cap_s), cntM = shard_counts(a.fcnt->n_lmain[L], lv.cap_s),
+                   cntC = shard_counts(a.fcnt->n_lrefl[L], lv.cap_s);
     for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
         uint32_t slot, cc;
         const uint32_t* list = nullptr;
-        const uint32_t* counts = a.fcnt->n_frames[L];
+        uint32_t counts = cntF;
         if (c < a.nsl * chA) {
             slot = c / chA;
             cc = c - slot * chA;
@@ -705,17 +718,16 @@ __global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L,
             slot = a.nsl + (c2 >= chM ? (uint32_t)SLOT_A : (uint32_t)SLOT_MAIN);
             cc = c2 >= chM ? c2 - chM : c2;
             list = lv.lmain;
-            counts = a.fcnt->n_lmain[L];
+            counts = cntM;
         } else {
             slot = a.nsl + (uint32_t)SLOT_C;
             cc = c - a.nsl * chA - 2u * chM;
             list = lv.lrefl;
-            counts = a.fcnt->n_lrefl[L];
+            counts = cntC;
         }
         const uint32_t shard = cc % RTU_SHARDS, k = cc / RTU_SHARDS;
         const uint32_t e = k * 64u + lane;
-        uint32_t ns = counts[shard * RTU_CSTRIDE];
-        if (ns > lv.cap_s) ns = lv.cap_s;
+        const uint32_t ns = count_of(counts, shard);
         const bool active = e < ns;
         const uint32_t fl = (active && list) ? list[(size_t)shard * lv.cap_s + e] : e;
         if (active && list) RTU_BYTES(4u);
@@ -740,10 +752,10 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L,
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
+    const uint32_t counts = shard_counts(a.fcnt->n_defer[ph], a.defer_cap_s);
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t ns = count_of(counts, shard);
         const uint32_t e = k * 64u + lane;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
@@ -826,9 +838,12 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
 // One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
 // lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
 // a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
+struct FrameRec {  // a frame's three records, fetched ahead of time (k_consume: the next chunk's while this one is evaluated)
+    float4 fa, fb, fc;
+};
 template <bool STATS, int TEX>
 __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
-                                              uint32_t f, int st_out[3], Counters& cnt) {
+                                              uint32_t f, int st_out[3], Counters& cnt, const FrameRec* pre = nullptr) {
     const DevScene& s = a.scene;
     const LevelBuffers& lv = a.lv[L];
     const bool haveNext = L + 1 < RTU_MAX_LEVELS;
@@ -837,7 +852,11 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     f3 cam_pos = ld3(a.frame.cam_pos);
     st_out[0] = st_out[1] = st_out[2] = RTU_CH_NONE;
     float4 fa = make_float4(0, 0, 0, 0), fb = fa, fc = fa;
-    if (active) { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; RTU_BYTES(TEXD ? 64u : 48u); }
+    if (active) {
+        if (pre) { fa = pre->fa; fb = pre->fb; fc = pre->fc; }
+        else { fa = lv.fa[f]; fb = lv.fb[f]; fc = lv.fc[f]; }
+        RTU_BYTES(TEXD ? 64u : 48u);
+    }
     const uint32_t info = __float_as_uint(fa.w);
     const f3 p = mk3(fa.x, fa.y, fa.z), N = mk3(fb.x, fb.y, fb.z), dir = mk3(fc.x, fc.y, fc.z);
     const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
@@ -872,6 +891,18 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
         const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
         uint32_t j = 0;  // index among the non-ambient lights
         const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
+        // A MATERIAL WITHOUT A SPECULAR COLOUR (walls, floors: `specular value="0"`) does not need its highlight: the light's term
+        // is (Illuminate * N.L) * (diffuse + specular * pow(N.H, glossiness)) (:152), and with specular = +-0 in every channel the
+        // second factor is `diffuse` bit for bit PROVIDED pow() is finite — +-0 * finite = +-0, and x + +-0 = x unless x is -0
+        // (excluded below) —: no half vector (a square root, three divisions), no N.H, no powf (~150 instructions on this
+        // device). pow(N.H, g) is finite when N.H is a number in [0, 1 + 1e-6] and 0 <= g <= 1e6. N.H = N . normalize(V + L) is a
+        // NaN exactly when N is (then N.L is too and the term is NaN whatever the second factor) or when the half vector is:
+        // V + L zero or NaN (the light straight behind the surface point as seen from the camera; the camera or a light AT the
+        // point) — the loop below takes the literal path then (`hh > 0` fails). The counting variant always takes the literal
+        // path: every test that compares the two variants checks this identity, NaN pixels included.
+        const bool noHighlight = !STATS && specular.x == 0.0f && specular.y == 0.0f && specular.z == 0.0f &&
+                                 m.glossiness >= 0.0f && m.glossiness <= 1e6f && __float_as_uint(diffuse.x) != 0x80000000u &&
+                                 __float_as_uint(diffuse.y) != 0x80000000u && __float_as_uint(diffuse.z) != 0x80000000u;
         for (uint32_t i = 0; i < s.n_lights; i++) {
             const RTU_CONST RtuLight& l = as_const(s.lights)[i];
             const f3 intensity = ld3(l.intensity);
@@ -883,11 +914,16 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
             const bool isDirect = l.type == RTU_LIGHT_DIRECT;
             const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
             const f3 lightDirection = norm3(-ldir);                       // :138
-            const f3 halfVector = norm3(viewDirection + lightDirection);  // :139
+            const f3 hsum = viewDirection + lightDirection;
             float NDotL = dot3(N, lightDirection);
-            float NDotH = dot3(N, halfVector);
             if (NDotL < 0.0f) NDotL = 0.0f;
-            if (NDotH < 0.0f) NDotH = 0.0f;
+            f3 second = diffuse;  // diffuse + specular * pow(N.H, glossiness) of a material without a specular colour
+            if (!(noHighlight && dot3(hsum, hsum) > 0.0f)) {
+                const f3 halfVector = norm3(hsum);  // :139
+                float NDotH = dot3(N, halfVector);
+                if (NDotH < 0.0f) NDotH = 0.0f;
+                second = diffuse + specular * powf(NDotH, m.glossiness);
+            }
             const bool behind = !STATS && j < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + j)) & 1u);  // no shadow ray was fired (make_info)
             const float sh = behind ? 1.0f : lv.fsh[(size_t)f * a.nsl + j];
             j++;
@@ -898,7 +934,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
                 const f3 d = lvec - p;
                 illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
             }
-            direct = direct + (illum * NDotL) * (diffuse + specular * powf(NDotH, m.glossiness));  // :152
+            direct = direct + (illum * NDotL) * second;  // :152
         }
     }
 
@@ -1038,12 +1074,29 @@ __global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, in
     const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
+    // the records of the wavefront's NEXT chunk are fetched before this one is evaluated: the kernel waits for memory half of its
+    // time (the records miss L2: every frame is read once), and a chunk's evaluation covers the next one's first round trip
+    FrameRec nxt;
+    nxt.fa = nxt.fb = nxt.fc = make_float4(0, 0, 0, 0);
+    const uint32_t counts = shard_counts(a.fcnt->n_frames[L], lv.cap_s);
+    auto fetch = [&](uint32_t c) {
+        if (c < chunks) {
+            const uint32_t shard = c % RTU_SHARDS, fl = (c / RTU_SHARDS) * 64u + lane;
+            if (fl < count_of(counts, shard)) {
+                const uint32_t f = shard * lv.cap_s + fl;
+                nxt.fa = lv.fa[f]; nxt.fb = lv.fb[f]; nxt.fc = lv.fc[f];
+            }
+        }
+    };
+    fetch(blockIdx.x);
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t fl = k * 64u + lane;
-        const bool active = fl < shard_count(a, L, shard);
+        const bool active = fl < count_of(counts, shard);
+        const FrameRec cur = nxt;
+        fetch(c + gridDim.x);
         int st[3];
-        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st, cnt);
+        consume_frame<STATS, TEX>(a, L, lane, active, shard, shard, fl, shard * lv.cap_s + fl, st, cnt, &cur);
     }
     flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L + 3);
 }

@@ -1136,3 +1136,61 @@ def test_stage2_grids_from_the_last_launch_are_only_a_hint(pkg, ctx, golden):
         assert np.array_equal(img.view(np.uint32), ref[name].view(np.uint32)), "stale grid hints changed the %s view" % name
         counts[name] = ctx.frame_counts()[1]
     assert max(counts["far"]) < 600 and max(counts["near"]) > 1200, "the two views do not straddle the threshold: %s" % counts
+
+
+def test_materials_without_a_specular_colour_skip_the_highlight_exactly(pkg, orc, tmp_path):
+    """k_consume leaves out half vector, N.H and powf for a material whose specular colour is +-0 — the second factor of a
+    light's term is then `diffuse` bit for bit, PROVIDED pow() is finite. Where that does not hold the literal path must be
+    taken: a light straight behind the surface point as seen from the camera (V + L = 0: the reference's half vector is 0/0
+    and the pixel NaN — odd resolution, camera on the axis, so the centre pixel is that case), a negative or an absurd
+    glossiness (pow infinite), a diffuse channel of -0. Fast variant == counting variant (which always takes the literal
+    path) == oracle, NaN pixels included; with one camera and with a batch."""
+    xml = tmp_path / "nospec.xml"
+    xml.write_text("""<xml><scene>
+      <object type="plane" name="floor" material="matte"><scale value="9"/></object>
+      <object type="sphere" name="s1" material="neg"><scale value="1.2"/><translate x="-4" y="3" z="1.2"/></object>
+      <object type="sphere" name="s2" material="huge"><scale value="1.2"/><translate x="4" y="3" z="1.2"/></object>
+      <object type="sphere" name="s3" material="mzero"><scale value="1.2"/><translate x="-4" y="-3" z="1.2"/></object>
+      <object type="sphere" name="s4" material="shiny"><scale value="1.2"/><translate x="4" y="-3" z="1.2"/></object>
+      <object type="sphere" name="s5" material="matte"><scale value="1.0"/><translate x="0" y="4" z="1.0"/></object>
+      <material type="blinn" name="matte"><diffuse r="0.7" g="0" b="0.4"/><specular value="0"/><glossiness value="25"/></material>
+      <material type="blinn" name="neg"><diffuse r="0.2" g="0.6" b="0.3"/><specular value="0"/><glossiness value="-3"/></material>
+      <material type="blinn" name="huge"><diffuse r="0.6" g="0.6" b="0.1"/><specular value="0"/><glossiness value="1e30"/></material>
+      <material type="blinn" name="mzero"><diffuse r="-0.0" g="0.5" b="-0.0"/><specular r="-0.0" g="0" b="0"/><glossiness value="10"/></material>
+      <material type="blinn" name="shiny"><diffuse r="0.3" g="0.3" b="0.6"/><specular value="0.8"/><glossiness value="40"/></material>
+      <light type="ambient" name="a"><intensity value="0.1"/></light>
+      <light type="point" name="below"><intensity value="40"/><position x="0" y="0" z="-10"/></light>
+      <light type="point" name="atcam"><intensity value="60"/><position x="0" y="0" z="10"/></light>
+      <light type="direct" name="d"><intensity value="0.5"/><direction x="0.3" y="0.2" z="-1"/></light>
+    </scene><camera><position x="0" y="0" z="10"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="60"/>
+      <width value="101"/><height value="101"/></camera></xml>""")
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 101, 101
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(scene)
+        cpu, cst = orc.render(scene, W, H, threads=8)
+        cnt, gst = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+        assert gst == cst
+        check_against(cnt, cpu, orc)
+        assert np.isnan(cpu[H // 2, W // 2, :3]).all(), "the centre pixel (light straight behind the floor) is not the 0/0 case any more"
+        fast, _ = ctx.render(pkg.frame_setup(scene.desc.camera, W, H))
+        same = (fast.view(np.uint32) == cnt.view(np.uint32)) | (np.isnan(fast) & np.isnan(cnt))
+        assert same.all(), "fast and counting variants differ at %d values" % int((~same).sum())
+        assert np.array_equal(np.isnan(fast), np.isnan(cnt))
+        d = pkg.hip.rtu_device_alloc(ctx._h, 2 * W * H * 16)
+        for attempt in range(8):
+            ctx.render_frames_device([pkg.frame_setup(scene.desc.camera, W, H)] * 2, d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as e:
+                assert e.code == pkg.RTU_ERR_CAPACITY
+        out = np.empty((2, H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+        pkg.hip.rtu_device_free(ctx._h, d)
+        for i in range(2):
+            same = (out[i].view(np.uint32) == cnt.view(np.uint32)) | (np.isnan(out[i]) & np.isnan(cnt))
+            assert same.all()
+    finally:
+        ctx.close()

@@ -706,6 +706,8 @@ __global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L,
     Counters cnt = {};
     const uint32_t cntF = shard_counts(a.fcnt->n_frames[L], lv.cap_s), cntM = shard_counts(a.fcnt->n_lmain[L], lv.cap_s),
                    cntC = shard_counts(a.fcnt->n_lrefl[L], lv.cap_s);
+    // (fetching the next chunk's record ahead, as k_consume does, was measured here: 245 -> 273 us — eight more registers cost the
+    // kernel its fifth wavefront per SIMD)
     for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
         uint32_t slot, cc;
         const uint32_t* list = nullptr;
@@ -838,8 +840,9 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
 // One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
 // lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
 // a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
-struct FrameRec {  // a frame's three records, fetched ahead of time (k_consume: the next chunk's while this one is evaluated)
-    float4 fa, fb, fc;
+struct FrameRec {  // a frame's three records and the Shadow() results of its first two lights, fetched ahead of time (k_consume:
+    float4 fa, fb, fc;  // the next chunk's while this one is evaluated)
+    float  sh0, sh1;
 };
 template <bool STATS, int TEX>
 __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32_t lane, bool active, uint32_t shard, uint32_t cshard, uint32_t fl,
@@ -925,7 +928,7 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
                 second = diffuse + specular * powf(NDotH, m.glossiness);
             }
             const bool behind = !STATS && j < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + j)) & 1u);  // no shadow ray was fired (make_info)
-            const float sh = behind ? 1.0f : lv.fsh[(size_t)f * a.nsl + j];
+            const float sh = behind ? 1.0f : (pre && j < 2u) ? (j == 0u ? pre->sh0 : pre->sh1) : lv.fsh[(size_t)f * a.nsl + j];
             j++;
             f3 illum;
             if (isDirect) {
@@ -1078,6 +1081,7 @@ __global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, in
     // time (the records miss L2: every frame is read once), and a chunk's evaluation covers the next one's first round trip
     FrameRec nxt;
     nxt.fa = nxt.fb = nxt.fc = make_float4(0, 0, 0, 0);
+    nxt.sh0 = nxt.sh1 = 1.0f;
     const uint32_t counts = shard_counts(a.fcnt->n_frames[L], lv.cap_s);
     auto fetch = [&](uint32_t c) {
         if (c < chunks) {
@@ -1085,6 +1089,8 @@ __global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, in
             if (fl < count_of(counts, shard)) {
                 const uint32_t f = shard * lv.cap_s + fl;
                 nxt.fa = lv.fa[f]; nxt.fb = lv.fb[f]; nxt.fc = lv.fc[f];
+                if (a.nsl > 0u) nxt.sh0 = lv.fsh[(size_t)f * a.nsl];  // (of a frame without RTU_FI_SH: written by nobody, read by nobody)
+                if (a.nsl > 1u) nxt.sh1 = lv.fsh[(size_t)f * a.nsl + 1u];
             }
         }
     };

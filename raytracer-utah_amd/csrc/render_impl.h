@@ -142,6 +142,14 @@ __device__ __forceinline__ uint32_t shard_counts(const uint32_t* counters, uint3
 __device__ __forceinline__ uint32_t count_of(uint32_t counts, uint32_t shard) {  // shard: wave-uniform
     return (uint32_t)__builtin_amdgcn_readlane((int)counts, (int)shard);
 }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // the largest shard population (wave-uniform result)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
 
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const KernelArgs& a, const Counters& cnt) {
@@ -319,10 +327,12 @@ __device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t
 // Geometry of a stage-2 launch: rays per wavefront from the (largest shard of the) list.
 struct NarrowGeom {
     uint32_t R, kmax, nmax, sum;
+    uint32_t counts;  // lane i: the population of shard i (count_of)
 };
 __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     uint32_t v = a.fcnt->n_defer[ph][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
     if (v > a.defer_cap_s) v = a.defer_cap_s;
+    const uint32_t mine = v;
     uint32_t sum = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -333,6 +343,7 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     NarrowGeom g;
     g.nmax = v;
     g.sum = sum;
+    g.counts = mine;
     // enough wavefronts to fill 256 CUs several times over before widening them
     // few rays: latency matters, eight lanes per ray; many rays: throughput matters, one lane per ray
     g.R = sum > (uint32_t)(a.frame.coop_threshold > 0 ? a.frame.coop_threshold : 70000) ? 64u : 8u;  // (round 2: the lists are shorter — masks — and so is the break-even: 40 / 70 / 100 / 120 k measured)
@@ -543,7 +554,7 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
-    const uint32_t counts = shard_counts(a.fcnt->n_defer[0], a.defer_cap_s);
+    const uint32_t counts = g.counts;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t ns = count_of(counts, shard);
@@ -583,8 +594,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[0][(shard) * RTU_CSTRIDE];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t ns = count_of(g.counts, shard);
         const uint32_t e = k * groups + grp;
         const bool valid = e < ns;
         uint32_t pix = 0;
@@ -692,20 +702,12 @@ __global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L,
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
     // shadow slots: every frame of the level; secondary slots: the frames listed for them (list_frame)
-    uint32_t vm = a.fcnt->n_lmain[L][(lane % RTU_SHARDS) * RTU_CSTRIDE], vc = a.fcnt->n_lrefl[L][(lane % RTU_SHARDS) * RTU_CSTRIDE];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)vm, off);
-        vm = o > vm ? o : vm;
-        o = (uint32_t)__shfl_xor((int)vc, off);
-        vc = o > vc ? o : vc;
-    }
-    const uint32_t chA = ((level_max_count(a, L) + 63u) / 64u) * RTU_SHARDS;  // 64-frame chunks, all shards
-    const uint32_t chM = ((vm + 63u) / 64u) * RTU_SHARDS, chC = ((vc + 63u) / 64u) * RTU_SHARDS;
+    const uint32_t cntF = shard_counts(a.fcnt->n_frames[L], lv.cap_s), cntM = shard_counts(a.fcnt->n_lmain[L], lv.cap_s),
+                   cntC = shard_counts(a.fcnt->n_lrefl[L], lv.cap_s);  // (each list's 64 counters: one load, for the geometry and for the chunks)
+    const uint32_t chA = ((wave_max(cntF) + 63u) / 64u) * RTU_SHARDS;  // 64-frame chunks, all shards
+    const uint32_t chM = ((wave_max(cntM) + 63u) / 64u) * RTU_SHARDS, chC = ((wave_max(cntC) + 63u) / 64u) * RTU_SHARDS;
     const uint32_t total = a.nsl * chA + 2u * chM + chC;
     Counters cnt = {};
-    const uint32_t cntF = shard_counts(a.fcnt->n_frames[L], lv.cap_s), cntM = shard_counts(a.fcnt->n_lmain[L], lv.cap_s),
-                   cntC = shard_counts(a.fcnt->n_lrefl[L], lv.cap_s);
     // (fetching the next chunk's record ahead, as k_consume does, was measured here: 245 -> 273 us — eight more registers cost the
     // kernel its fifth wavefront per SIMD)
     for (uint32_t c = blockIdx.x; c < total; c += gridDim.x) {
@@ -754,7 +756,7 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L,
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
-    const uint32_t counts = shard_counts(a.fcnt->n_defer[ph], a.defer_cap_s);
+    const uint32_t counts = g.counts;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t ns = count_of(counts, shard);
@@ -786,8 +788,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
-        uint32_t ns = a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE];
-        if (ns > a.defer_cap_s) ns = a.defer_cap_s;
+        const uint32_t ns = count_of(g.counts, shard);
         const uint32_t e = k * groups + grp;
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
@@ -1074,7 +1075,8 @@ __global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, in
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 3);
     const LevelBuffers& lv = a.lv[L];
     const uint32_t lane = threadIdx.x;
-    const uint32_t kmax = (level_max_count(a, L) + 63u) / 64u;
+    const uint32_t counts = shard_counts(a.fcnt->n_frames[L], lv.cap_s);
+    const uint32_t kmax = (wave_max(counts) + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
     // the records of the wavefront's NEXT chunk are fetched before this one is evaluated: the kernel waits for memory half of its
@@ -1082,7 +1084,6 @@ __global__ void __launch_bounds__(64) RTU_OCC_CONSUME k_consume(KernelArgs a, in
     FrameRec nxt;
     nxt.fa = nxt.fb = nxt.fc = make_float4(0, 0, 0, 0);
     nxt.sh0 = nxt.sh1 = 1.0f;
-    const uint32_t counts = shard_counts(a.fcnt->n_frames[L], lv.cap_s);
     auto fetch = [&](uint32_t c) {
         if (c < chunks) {
             const uint32_t shard = c % RTU_SHARDS, fl = (c / RTU_SHARDS) * 64u + lane;
@@ -1158,18 +1159,13 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
     const Stamp stamp(a, RTU_TL_COMBINE0 + L);
     const LevelBuffers& lv = a.lv[L];
     // only the frames k_consume listed as waiting for children
-    uint32_t pmax = a.fcnt->n_pending[L][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)pmax, off);
-        pmax = o > pmax ? o : pmax;
-    }
-    const uint32_t chunks = ((pmax + 63u) / 64u) * RTU_SHARDS;
+    const uint32_t counts = shard_counts(a.fcnt->n_pending[L], lv.cap_s);
+    const uint32_t chunks = ((wave_max(counts) + 63u) / 64u) * RTU_SHARDS;
     Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t shard = c % RTU_SHARDS, k = c / RTU_SHARDS;
         const uint32_t e = k * 64u + threadIdx.x;
-        if (e >= a.fcnt->n_pending[L][(shard) * RTU_CSTRIDE]) continue;
+        if (e >= count_of(counts, shard)) continue;
         const uint32_t f = shard * lv.cap_s + lv.fpend[(size_t)shard * lv.cap_s + e];
         RTU_BYTES(4u);
         combine_frame<TEX>(a, L, f, cnt);

@@ -874,7 +874,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
             RTU_HIP(ctx, hipMalloc((void**)&ctx->occ, need * sizeof(uint32_t)));
             ctx->occ_cap = need;
         }
-        a.occ = ctx->occ;
+        a.occ = a.occ_words ? ctx->occ : nullptr;  // (a shard without rows has no tiles: nothing is launched at all)
     }
     a.tiles_x = tiles_x;
     a.tiles_per_image = tiles_x * bands;

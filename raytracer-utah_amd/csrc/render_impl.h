@@ -389,14 +389,15 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         }
         if (a.cover) {  // inside a mesh's rectangle: does any of its triangles reach this 8x8 tile? (k_mesh_cover)
             const uint32_t tile = (uint32_t)(y >> 3) * a.tiles_xf + (uint32_t)(x >> 3);
-            for (uint32_t c = 0; c < s.n_cover; c++) {
-                const uint32_t k = (uint32_t)s.cover_node[c];
+            const uint32_t ncov = s.n_cover + s.n_pcover;  // masked mesh nodes, then masked plane nodes
+            for (uint32_t c = 0; c < ncov; c++) {
+                const uint32_t k = (uint32_t)(c < s.n_cover ? s.cover_node[c] : s.pcover_node[c - s.n_cover]);
                 const bool inside = valid && k < 64u && !((skip >> k) & 1ull);  // inside the mesh's rectangle
                 if (!__any(inside)) continue;                                    // (most wavefronts: no load at all)
-                const RTU_CONST uint32_t* m = as_const(a.cover) + ((size_t)sidx * s.n_cover + c) * (1u + a.cover_words);
+                const RTU_CONST uint32_t* m = as_const(a.cover) + ((size_t)sidx * ncov + c) * (1u + a.cover_words);
                 if (inside && m[0] == 0u && !((m[1u + (tile >> 5)] >> (tile & 31u)) & 1u)) skip |= 1ull << k;
             }
-            if (CNTD && leader && valid) cnt.t_bytes += 4u * s.n_cover;  // (the lane's word of each mask it looked at, at most)
+            if (CNTD && leader && valid) cnt.t_bytes += 4u * ncov;  // (the lane's word of each mask it looked at, at most)
         }
         if (CNTD && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) cnt.t_bytes += 16u * nn;  // wave-uniform: once per wavefront
         if (s.n_nodes <= 64u && __all(!valid || (skip & s.obj_mask) == s.obj_mask)) {
@@ -1391,7 +1392,7 @@ __global__ void __launch_bounds__(64) k_node_rects(KernelArgs a, uint32_t entrie
 __global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entries) {
     const uint32_t e = blockIdx.y / a.scene.n_cover, c = blockIdx.y % a.scene.n_cover;
     if (e >= entries) return;
-    uint32_t* m = a.cover + ((size_t)e * a.scene.n_cover + c) * (1u + a.cover_words);
+    uint32_t* m = a.cover + ((size_t)e * (a.scene.n_cover + a.scene.n_pcover) + c) * (1u + a.cover_words);
     // the 256 triangles of a workgroup mark a copy of the mask in LDS; its non-zero words are then added to the mask in memory
     // (device-scope atomics are served one after the other per cache line: 6320 triangles x 6 tiles straight into 32 lines took 45 us)
     extern __shared__ uint32_t s_mask[];
@@ -1452,6 +1453,106 @@ __global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entri
     }
 }
 
+// COVERAGE MASK OF A PLANE node (slots n_cover.. of KernelArgs::cover): one thread per 8x8 tile of the whole image, per camera of
+// the launch and masked plane. A Plane is the unit square of its node (objFunctions.cpp:107-140: the hit must lie strictly
+// inside (-1,1)^2 of the node's z = 0); the screen RECTANGLE of a square seen at an angle is mostly air (the headline's ground
+// is a diamond: half of its rectangle). So the square itself is projected: its four world-space corners (upload, binary64), each
+// pushed outwards along both of its edges by the cull margin for this camera (delta = 1e-4 max(scene scale, |camera|): a hundred
+// times the rounding of the reference's own ray / square arithmetic, as for the node bounds) divided by the sine of the corner's
+// angle, through the camera in binary64 like the node bound's corners; a tile — widened by two pixels on every side — is marked
+// unless a separating line is found: the quadrilateral's bounding box, or one of its four edges with the whole tile beyond it.
+// A corner at or behind the camera plane, a sliver of a corner (sine < 0.05) or a NaN makes the mask unusable (word 0 = 1).
+__global__ void __launch_bounds__(256) k_plane_cover(KernelArgs a, uint32_t entries) {
+    const DevScene& s = a.scene;
+    const uint32_t e = blockIdx.y / s.n_pcover, c = blockIdx.y % s.n_pcover;
+    if (e >= entries) return;
+    uint32_t* m = a.cover + ((size_t)e * (s.n_cover + s.n_pcover) + s.n_cover + c) * (1u + a.cover_words);
+    __shared__ double s_v[4][2];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    if (threadIdx.x < 4u) {
+        const uint32_t i = threadIdx.x;
+        const float* cp = a.frame_batch ? a.cam[e].pos : a.frame.cam_pos;
+        const float* co = a.frame_batch ? a.cam[e].origin : a.frame.origin;
+        const float* cu = a.frame_batch ? a.cam[e].u : a.frame.u;
+        const float* cv = a.frame_batch ? a.cam[e].v : a.frame.v;
+        const double P[3] = {cp[0], cp[1], cp[2]};
+        const double U[3] = {cu[0], cu[1], cu[2]}, V[3] = {cv[0], cv[1], cv[2]};
+        const double O[3] = {co[0] - P[0], co[1] - P[1], co[2] - P[2]};
+        const double det = U[0] * (V[1] * O[2] - V[2] * O[1]) - V[0] * (U[1] * O[2] - U[2] * O[1]) + O[0] * (U[1] * V[2] - U[2] * V[1]);
+        const double pm = fmax(fabs(P[0]), fmax(fabs(P[1]), fabs(P[2])));
+        const double delta = 1e-4 * fmax((double)s.wscale, pm);
+        const float (*q)[3] = s.pcover_quad[c];
+        const uint32_t ip = (i + 3u) & 3u, in = (i + 1u) & 3u;
+        double w[3], ua[3], ub[3], la = 0, lb = 0, big = 0;
+        for (int k = 0; k < 3; k++) {
+            ua[k] = (double)q[i][k] - (double)q[ip][k];  // away from the previous corner
+            ub[k] = (double)q[i][k] - (double)q[in][k];  // away from the next corner
+            la += ua[k] * ua[k];
+            lb += ub[k] * ub[k];
+            big = fmax(big, fabs((double)q[i][k]));
+        }
+        la = sqrt(la);
+        lb = sqrt(lb);
+        double dotab = 0;
+        for (int k = 0; k < 3; k++) { ua[k] /= la; ub[k] /= lb; dotab += ua[k] * ub[k]; }
+        const double sine = sqrt(fmax(0.0, 1.0 - dotab * dotab));
+        bool ok = det != 0.0 && la > 0.0 && lb > 0.0 && sine >= 0.05;
+        const double push = (delta + 1e-5 * big) / fmax(sine, 0.05);
+        for (int k = 0; k < 3; k++) w[k] = (double)q[i][k] + (ua[k] + ub[k]) * push - P[k];
+        const double da = w[0] * (V[1] * O[2] - V[2] * O[1]) - V[0] * (w[1] * O[2] - w[2] * O[1]) + O[0] * (w[1] * V[2] - w[2] * V[1]);
+        const double db = U[0] * (w[1] * O[2] - w[2] * O[1]) - w[0] * (U[1] * O[2] - U[2] * O[1]) + O[0] * (U[1] * w[2] - U[2] * w[1]);
+        const double dc = U[0] * (V[1] * w[2] - V[2] * w[1]) - V[0] * (U[1] * w[2] - U[2] * w[1]) + w[0] * (U[1] * V[2] - U[2] * V[1]);
+        const double cc = dc / det;  // depth along the view axis in units of the image-plane distance
+        if (!(cc > 1e-3)) ok = false;
+        const double pa = da / dc, pb = db / dc;  // pixel x lies on the ray through a = x + 0.5
+        if (!(pa == pa) || !(pb == pb) || fabs(pa) > 1e9 || fabs(pb) > 1e9) ok = false;
+        s_v[i][0] = pa;
+        s_v[i][1] = pb;
+        if (!ok) s_bad = 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) m[0] = 1u;  // this mask decides nothing
+        return;
+    }
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tiles_y = (uint32_t)((a.frame.height + 7) / 8);
+    bool mark = false;
+    if (tile < a.tiles_xf * tiles_y) {
+        const uint32_t ty = tile / a.tiles_xf, tx = tile - ty * a.tiles_xf;
+        // the tile's pixels x0 .. x0 + 7 see the rays a in [x0 + 0.5, x0 + 7.5]; two pixels of slack on every side
+        const double rx0 = (double)(tx * 8u) + 0.5 - 2.0, rx1 = (double)(tx * 8u) + 7.5 + 2.0;
+        const double ry0 = (double)(ty * 8u) + 0.5 - 2.0, ry1 = (double)(ty * 8u) + 7.5 + 2.0;
+        double amin = s_v[0][0], amax = amin, bmin = s_v[0][1], bmax = bmin, area2 = 0;
+        for (int i = 0; i < 4; i++) {
+            amin = fmin(amin, s_v[i][0]); amax = fmax(amax, s_v[i][0]);
+            bmin = fmin(bmin, s_v[i][1]); bmax = fmax(bmax, s_v[i][1]);
+            const int j = (i + 1) & 3;
+            area2 += s_v[i][0] * s_v[j][1] - s_v[j][0] * s_v[i][1];
+        }
+        mark = !(amax < rx0 || amin > rx1 || bmax < ry0 || bmin > ry1);
+        if (mark && fabs(area2) > 1e-6) {  // (an edge-on square has no inside: its bounding box is all there is)
+            const double sgn = area2 > 0 ? 1.0 : -1.0;
+            for (int i = 0; i < 4 && mark; i++) {
+                const int j = (i + 1) & 3;
+                const double ex = s_v[j][0] - s_v[i][0], ey = s_v[j][1] - s_v[i][1];
+                // inside is where sgn * cross(edge, q - v_i) >= 0: the tile is beyond this edge when all four of its corners are outside
+                const double c00 = sgn * (ex * (ry0 - s_v[i][1]) - ey * (rx0 - s_v[i][0])), c10 = sgn * (ex * (ry0 - s_v[i][1]) - ey * (rx1 - s_v[i][0]));
+                const double c01 = sgn * (ex * (ry1 - s_v[i][1]) - ey * (rx0 - s_v[i][0])), c11 = sgn * (ex * (ry1 - s_v[i][1]) - ey * (rx1 - s_v[i][0]));
+                if (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0) mark = false;
+            }
+        }
+    }
+    const unsigned long long bits = __ballot(mark);
+    if ((threadIdx.x & 63u) == 0u) {  // a wavefront's 64 tiles are two whole words of the mask
+        const uint32_t w0 = (blockIdx.x * 256u + threadIdx.x) >> 5;
+        if (w0 < a.cover_words) m[1u + w0] = (uint32_t)bits;
+        if (w0 + 1u < a.cover_words) m[2u + w0] = (uint32_t)(bits >> 32);
+    }
+}
+
 // TILE OCCUPANCY (KernelArgs::occ): one thread per 8x8 tile of the shard, per camera of the launch: is any valid pixel of the tile
 // inside the screen rectangle of an object node (k_node_rects) and, where that node is a mesh with a usable coverage mask
 // (k_mesh_cover), in a tile the mask marks? Exactly the pixels primary_pixel's own rectangle / mask test would keep: a tile with
@@ -1474,9 +1575,9 @@ __global__ void __launch_bounds__(64) k_tile_occ(KernelArgs a, uint32_t entries)
             if (!(x0 < r.z && x1 > r.x && y0 < r.w && y1 > r.y)) continue;  // no pixel of the tile inside the rectangle
             bool masked_out = false;
             if (a.cover)
-                for (uint32_t c = 0; c < s.n_cover; c++)
-                    if ((uint32_t)s.cover_node[c] == k) {
-                        const uint32_t* m = a.cover + ((size_t)e * s.n_cover + c) * (1u + a.cover_words);
+                for (uint32_t c = 0; c < s.n_cover + s.n_pcover; c++)
+                    if ((uint32_t)(c < s.n_cover ? s.cover_node[c] : s.pcover_node[c - s.n_cover]) == k) {
+                        const uint32_t* m = a.cover + ((size_t)e * (s.n_cover + s.n_pcover) + c) * (1u + a.cover_words);
                         if (m[0] == 0u && !((m[1u + (gtile >> 5)] >> (gtile & 31u)) & 1u)) masked_out = true;
                     }
             if (!masked_out) occ = true;
@@ -1536,7 +1637,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
-        if (!SMPD && a.cover) hipLaunchKernelGGL(k_mesh_cover, dim3((a.cover_faces + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_cover), dim3(256), a.cover_words * sizeof(uint32_t), stream, a, (BATD ? a.batch : 1u));
+        if (!SMPD && a.cover && a.scene.n_cover) hipLaunchKernelGGL(k_mesh_cover, dim3((a.cover_faces + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_cover), dim3(256), a.cover_words * sizeof(uint32_t), stream, a, (BATD ? a.batch : 1u));
+        if (!SMPD && a.cover && a.scene.n_pcover) hipLaunchKernelGGL(k_plane_cover, dim3((a.cover_words * 32u + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_pcover), dim3(256), 0, stream, a, (BATD ? a.batch : 1u));
         if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred

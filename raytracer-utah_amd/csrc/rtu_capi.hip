@@ -847,11 +847,11 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.scene.dbg = ctx->dbg;
     a.counters = stats ? ctx->counters : nullptr;
     a.node_rects = (stats != 1 && frame->samples == 0 && ctx->dscene.node_bounds) ? ctx->node_rects : nullptr;
-    if (a.node_rects && ctx->dscene.n_cover && !gi && ((size_t)((frame->width + 7) / 8) * (size_t)((frame->height + 7) / 8) + 31u) / 32u <= 12288u) {  // (the mask has to fit k_mesh_cover's LDS copy)
+    if (a.node_rects && (ctx->dscene.n_cover + ctx->dscene.n_pcover) && !gi && ((size_t)((frame->width + 7) / 8) * (size_t)((frame->height + 7) / 8) + 31u) / 32u <= 12288u) {  // (the mask has to fit k_mesh_cover's LDS copy)
         a.tiles_xf = (uint32_t)((frame->width + 7) / 8);
         a.cover_words = (a.tiles_xf * (uint32_t)((frame->height + 7) / 8) + 31u) / 32u;
         a.cover_faces = ctx->cover_faces;
-        const size_t need = (size_t)batch * ctx->dscene.n_cover * (1u + a.cover_words);
+        const size_t need = (size_t)batch * (ctx->dscene.n_cover + ctx->dscene.n_pcover) * (1u + a.cover_words);
         if (need > ctx->cover_cap) {
             RTU_HIP(ctx, hipStreamSynchronize(stream));  // (first launch at this size only) nothing may still read the old masks
             if (ctx->cover) (void)hipFree(ctx->cover);
@@ -1382,6 +1382,28 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             ds.cover_nf[ds.n_cover - 1] = m.nf;
             cover_host.push_back(std::move(boxes));
         }
+    }
+    // plane nodes with a coverage mask: the corners of the node's unit square in world space (k_plane_cover)
+    ds.n_pcover = 0;
+    for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++) {
+        if (s->nodes[i].obj_type != RTU_OBJ_PLANE || ds.n_pcover >= RTU_MAX_PCOVER) continue;
+        static const double sq[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+        float quad[4][3];
+        bool finite = true;
+        for (int c = 0; c < 4; c++) {
+            double p[3] = {sq[c][0], sq[c][1], 0.0};
+            for (int j = (int)i; j >= 0; j = s->nodes[j].parent) {
+                const RtuNode& t = s->nodes[j];
+                const double q[3] = {p[0] * t.tm[0] + p[1] * t.tm[3] + p[2] * t.tm[6] + t.pos[0], p[0] * t.tm[1] + p[1] * t.tm[4] + p[2] * t.tm[7] + t.pos[1],
+                                     p[0] * t.tm[2] + p[1] * t.tm[5] + p[2] * t.tm[8] + t.pos[2]};
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            }
+            for (int k = 0; k < 3; k++) { quad[c][k] = (float)p[k]; finite = finite && std::isfinite(quad[c][k]); }
+        }
+        if (!finite) continue;  // NaN / infinite transformation: no mask (the node's rectangle is the whole image as well)
+        ds.pcover_node[ds.n_pcover] = (int32_t)i;
+        memcpy(ds.pcover_quad[ds.n_pcover], quad, sizeof quad);
+        ds.n_pcover++;
     }
     if ((rc = build_light_masks(ctx, s, cover_host, wscale, ds)) != RTU_OK) return rc;
     ds.obj_mask = 0;

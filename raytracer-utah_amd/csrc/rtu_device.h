@@ -92,6 +92,7 @@ struct DevMesh {
     float    scale;             // largest |coordinate| of the mesh's bounding box (cull margin, rtu_intersect.h)
 };
 
+#define RTU_MAX_PCOVER 8      // plane nodes that get a coverage mask for primary rays
 struct DevNode {                // one scene-graph node (wave-uniform data)
     float   tm[9], itm[9], pos[3];
     int32_t parent, obj_type, mesh_id, material_id, depth;
@@ -145,6 +146,11 @@ struct DevScene {
     const DevLightMask* lmask;  // [min(non-ambient lights, RTU_LMASK_LIGHTS)][n_cover] shadow masks, or nullptr
     const float4* cover_box[8]; // per masked mesh node: the WORLD-space box of every triangle, 2 float4 {lo, -} {hi, -} (computed at upload in
     uint32_t cover_nf[8];       //   binary64, rounded outwards), and the triangle count   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
+    // PLANE nodes get a coverage mask too (slots n_cover .. n_cover + n_pcover - 1 of KernelArgs::cover): a Plane is the unit square of
+    // its node, and the screen rectangle of a square seen at an angle is mostly air (k_plane_cover projects the square itself)
+    uint32_t n_pcover, pad_pc;
+    int32_t  pcover_node[RTU_MAX_PCOVER];
+    float    pcover_quad[RTU_MAX_PCOVER][4][3];  // the square's corners (-1,-1) (1,-1) (1,1) (-1,1) through the node's chain of transformations (binary64, rounded)
     uint32_t dbg;               // experiment switches (rtu_debug_flags), as KernelArgs::dbg
     uint32_t node_bounds;       // 0: node-level bounds off (test hook rtu_debug_node_bounds; results must not change)
     float    background[3];     // background.Sample(...) for an untextured / NULL-map background

@@ -1194,3 +1194,79 @@ def test_materials_without_a_specular_colour_skip_the_highlight_exactly(pkg, orc
             assert same.all()
     finally:
         ctx.close()
+
+
+def test_plane_coverage_masks_in_awkward_views(pkg, orc, tmp_path):
+    """k_plane_cover projects a Plane node's unit square itself (its screen rectangle is mostly air when the square is seen at an
+    angle) and k_primary skips the node in tiles the projection cannot reach. Where the argument is thinnest: a square seen
+    almost edge-on (no inside: only its bounding box decides), squares under nested non-uniform scales and a shear-like chain
+    (parallelograms, one of them a sliver: mask unusable), a square with a corner behind the camera (unusable), a camera a hair
+    above a square's edge, pixels along the squares' edges at a ragged resolution. Fast variant == counting variant (which uses
+    neither rectangles nor masks) == oracle, one camera at a time and as a batch."""
+    xml = tmp_path / "planes.xml"
+    xml.write_text("""<xml><scene>
+      <object type="plane" name="floor" material="a"><scale value="6"/><rotate angle="-45" z="1"/><translate x="1" y="2" z="0"/></object>
+      <object name="g1"><scale x="1.8" y="0.6" z="1"/><rotate angle="35" z="1"/><rotate angle="20" x="1"/><translate x="-3" y="1" z="2"/>
+        <object type="plane" name="tilted" material="b"><scale x="0.4" y="2.5" z="1"/><rotate angle="50" z="1"/><rotate angle="-30" y="1"/></object>
+      </object>
+      <object name="g2"><scale x="3" y="0.05" z="1"/><rotate angle="44" z="1"/><translate x="3" y="-1" z="1"/>
+        <object type="plane" name="sliver" material="c"><rotate angle="45.5" z="1"/><scale x="1" y="14" z="1"/></object>
+      </object>
+      <object type="plane" name="wall" material="c"><scale value="4"/><rotate angle="90" x="1"/><translate x="0" y="9" z="3"/></object>
+      <object type="sphere" name="ball" material="g"><scale value="1.1"/><translate x="0.5" y="1.5" z="1.1"/></object>
+      <material type="blinn" name="a"><diffuse r="0.7" g="0.7" b="0.5"/><specular value="0"/></material>
+      <material type="blinn" name="b"><diffuse r="0.3" g="0.6" b="0.8"/><specular value="0.5"/><glossiness value="30"/><reflection value="0.3"/></material>
+      <material type="blinn" name="c"><diffuse r="0.8" g="0.3" b="0.3"/><specular value="0.2"/><glossiness value="10"/></material>
+      <material type="blinn" name="g"><diffuse value="0.05"/><specular value="0.8"/><glossiness value="60"/><refraction index="1.4" value="0.9"/></material>
+      <light type="ambient" name="amb"><intensity value="0.15"/></light>
+      <light type="point" name="p"><intensity value="120"/><position x="-2" y="-6" z="12"/></light>
+      <light type="direct" name="d"><intensity value="0.6"/><direction x="0.4" y="0.5" z="-1"/></light>
+    </scene><camera><position x="0" y="-16" z="5"/><target x="0" y="1" z="1"/><up x="0" y="0" z="1"/><fov value="48"/>
+      <width value="171"/><height value="113"/></camera></xml>""")
+    scene = pkg.Scene.from_xml(str(xml))
+    W, H = 171, 113
+    views = [((0, -16, 5), (0, 1, 1)),            # all squares in view
+             ((0, -16, 0.02), (0, 1, 0.02)),      # the floor almost edge-on
+             ((1, 2, 14), (1.001, 2.001, 0)),     # straight down at the floor
+             ((0.5, -3.0, 0.4), (1, 2, 0.2)),     # over the floor: corners behind the camera
+             ((1 + 6 * 0.7071 + 0.01, 2 + 0.0, 0.05), (1, 2, 0)),  # a hair above and beyond a corner of the floor
+             ((-9, -4, 6), (-3, 1, 2))]           # towards the tilted parallelogram
+    cams = []
+    for pos, tgt in views:
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        d = [t - p for p, t in zip(pos, tgt)]
+        for i in range(3):
+            cam.pos[i] = pos[i]
+            cam.dir[i] = d[i]
+        cams.append(cam)
+    ctx = pkg.Context(0)
+    try:
+        ctx.upload(scene)
+        refs = []
+        for i, cam in enumerate(cams):
+            cnt, gst = ctx.render(pkg.frame_setup(cam, W, H, collect_stats=True), stats=True)
+            if i in (0, 3):
+                s2 = pkg.Scene.from_xml(str(xml))
+                for k in range(3):
+                    s2.desc.camera.pos[k], s2.desc.camera.dir[k] = cam.pos[k], cam.dir[k]
+                cpu, cst = orc.render(s2, W, H, threads=8)
+                check_against(cnt, cpu, orc)
+                assert gst == cst
+            fast, _ = ctx.render(pkg.frame_setup(cam, W, H))
+            assert np.array_equal(fast.view(np.uint32), cnt.view(np.uint32)), "view %d: fast and counting variants differ" % i
+            refs.append(cnt)
+        d = pkg.hip.rtu_device_alloc(ctx._h, len(cams) * W * H * 16)
+        for attempt in range(17):
+            ctx.render_frames_device([pkg.frame_setup(c, W, H) for c in cams], d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as e:
+                assert e.code == pkg.RTU_ERR_CAPACITY and attempt < 16
+        out = np.empty((len(cams), H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+        pkg.hip.rtu_device_free(ctx._h, d)
+        for i in range(len(cams)):
+            assert np.array_equal(out[i].view(np.uint32), refs[i].view(np.uint32)), "batch: view %d differs" % i
+    finally:
+        ctx.close()

@@ -1340,9 +1340,9 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
 // primary ray can come within the cull margin of the node's world-space bound — the eight corners of the bound, widened by
 // delta = 1e-4 * max(scene scale, |camera|), projected through the camera in binary64, two pixels of slack on every side.
 // A corner at or behind the camera plane makes the rectangle the whole image. One lane per (camera, node).
-__global__ void __launch_bounds__(64) k_node_rects(KernelArgs a, uint32_t entries) {
+__device__ __forceinline__ void node_rects_body(const KernelArgs& a, uint32_t entries) {
     const uint32_t n_nodes = a.scene.n_nodes;
-    for (uint32_t i = threadIdx.x; i < entries * n_nodes; i += 64u) {
+    for (uint32_t i = threadIdx.x; i < entries * n_nodes; i += blockDim.x) {
         const uint32_t e = i / n_nodes, k = i - e * n_nodes;
         const DevNode& n = a.scene.nodes[k];
         int4 r = make_int4(0, 0, a.frame.width, a.frame.height);
@@ -1389,9 +1389,9 @@ __global__ void __launch_bounds__(64) k_node_rects(KernelArgs a, uint32_t entrie
 // box in world space (its vertices through the node's chain of transformations, computed once at upload), widened by the cull margin
 // for this camera, is projected like the node bound in k_node_rects; every 8x8 tile its pixel rectangle (two pixels of slack) touches
 // gets its bit. A primary ray that hits the triangle has its hit point in that box, so its pixel is in a marked tile.
-__global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entries) {
-    const uint32_t e = blockIdx.y / a.scene.n_cover, c = blockIdx.y % a.scene.n_cover;
-    if (e >= entries) return;
+__device__ __forceinline__ void mesh_cover_body(const KernelArgs& a, uint32_t entries, uint32_t by) {
+    const uint32_t e = by / a.scene.n_cover, c = by % a.scene.n_cover;
+    if (e >= entries || blockIdx.x * 256u >= a.scene.cover_nf[c]) return;  // (the grid is as wide as the widest role of k_prelude)
     uint32_t* m = a.cover + ((size_t)e * (a.scene.n_cover + a.scene.n_pcover) + c) * (1u + a.cover_words);
     // the 256 triangles of a workgroup mark a copy of the mask in LDS; its non-zero words are then added to the mask in memory
     // (device-scope atomics are served one after the other per cache line: 6320 triangles x 6 tiles straight into 32 lines took 45 us)
@@ -1462,10 +1462,10 @@ __global__ void __launch_bounds__(256) k_mesh_cover(KernelArgs a, uint32_t entri
 // angle, through the camera in binary64 like the node bound's corners; a tile — widened by two pixels on every side — is marked
 // unless a separating line is found: the quadrilateral's bounding box, or one of its four edges with the whole tile beyond it.
 // A corner at or behind the camera plane, a sliver of a corner (sine < 0.05) or a NaN makes the mask unusable (word 0 = 1).
-__global__ void __launch_bounds__(256) k_plane_cover(KernelArgs a, uint32_t entries) {
+__device__ __forceinline__ void plane_cover_body(const KernelArgs& a, uint32_t entries, uint32_t by) {
     const DevScene& s = a.scene;
-    const uint32_t e = blockIdx.y / s.n_pcover, c = blockIdx.y % s.n_pcover;
-    if (e >= entries) return;
+    const uint32_t e = by / s.n_pcover, c = by % s.n_pcover;
+    if (e >= entries || blockIdx.x * 256u >= a.cover_words * 32u) return;
     uint32_t* m = a.cover + ((size_t)e * (s.n_cover + s.n_pcover) + s.n_cover + c) * (1u + a.cover_words);
     __shared__ double s_v[4][2];
     __shared__ int s_bad;
@@ -1553,6 +1553,17 @@ __global__ void __launch_bounds__(256) k_plane_cover(KernelArgs a, uint32_t entr
     }
 }
 
+// THE PRELUDE of a recipe-W launch sequence in ONE launch (three launches of a few microseconds each were 6 % of a single frame):
+// blockIdx.y selects the role — the coverage mask of (camera, masked mesh) from the triangle boxes, of (camera, masked plane)
+// from the square's corners, or, in the last row, the screen rectangles of the node-level bounds (one block). The roles do not
+// depend on each other; k_tile_occ, which needs all three, is the next launch.
+__global__ void __launch_bounds__(256) k_prelude(KernelArgs a, uint32_t entries) {
+    const uint32_t nm = a.cover ? entries * a.scene.n_cover : 0u, np = a.cover ? entries * a.scene.n_pcover : 0u;
+    if (blockIdx.y < nm) mesh_cover_body(a, entries, blockIdx.y);
+    else if (blockIdx.y < nm + np) plane_cover_body(a, entries, blockIdx.y - nm);
+    else if (blockIdx.x == 0u) node_rects_body(a, entries);
+}
+
 // TILE OCCUPANCY (KernelArgs::occ): one thread per 8x8 tile of the shard, per camera of the launch: is any valid pixel of the tile
 // inside the screen rectangle of an object node (k_node_rects) and, where that node is a mesh with a usable coverage mask
 // (k_mesh_cover), in a tile the mask marks? Exactly the pixels primary_pixel's own rectangle / mask test would keep: a tile with
@@ -1636,9 +1647,14 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     } else if (stats) {
         if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
-        if (!SMPD && a.node_rects) hipLaunchKernelGGL(k_node_rects, dim3(1), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
-        if (!SMPD && a.cover && a.scene.n_cover) hipLaunchKernelGGL(k_mesh_cover, dim3((a.cover_faces + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_cover), dim3(256), a.cover_words * sizeof(uint32_t), stream, a, (BATD ? a.batch : 1u));
-        if (!SMPD && a.cover && a.scene.n_pcover) hipLaunchKernelGGL(k_plane_cover, dim3((a.cover_words * 32u + 255u) / 256u, (BATD ? a.batch : 1u) * a.scene.n_pcover), dim3(256), 0, stream, a, (BATD ? a.batch : 1u));
+        if (!SMPD && a.node_rects) {
+            const uint32_t entries = BATD ? a.batch : 1u;
+            const uint32_t rows = (a.cover ? entries * (a.scene.n_cover + a.scene.n_pcover) : 0u) + 1u;
+            uint32_t gx = 1u;
+            if (a.cover && a.scene.n_cover) gx = (a.cover_faces + 255u) / 256u > gx ? (a.cover_faces + 255u) / 256u : gx;
+            if (a.cover && a.scene.n_pcover) gx = (a.cover_words * 32u + 255u) / 256u > gx ? (a.cover_words * 32u + 255u) / 256u : gx;
+            hipLaunchKernelGGL(k_prelude, dim3(gx, rows), dim3(256), a.cover ? a.cover_words * sizeof(uint32_t) : 0, stream, a, entries);
+        }
         if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred

@@ -29,7 +29,7 @@ def slot_names(rows):
     for did, name in rows:
         m = re.search(r"::(k_\w+)<([^>]*)>", name)
         if not m:
-            if "k_node_rects" in name:
+            if "k_node_rects" in name or "k_prelude" in name:
                 seq.clear()
             continue
         k, targs = m.group(1), [t.strip() for t in m.group(2).split(",")]

@@ -379,7 +379,9 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     // node-level bounds of a primary ray (recipe W): the pixel against every node's screen rectangle for this camera
     // (k_node_rects). A wavefront whose pixels lie outside every rectangle has nothing to trace: background, done.
     unsigned long long skip = 0;
-    const bool rects = !STATS && !SMPD && a.node_rects != nullptr;
+    // (stage 1 only: a deferred pixel has passed its rectangles and masks already; stage 2, where every lane has its own camera
+    // entry and the lookups would be a dozen per-lane loads, bounds its ray in world space like any other ray — trace())
+    const bool rects = !STATS && !SMPD && DEFER && a.node_rects != nullptr;
     if (rects) {
         const RTU_CONST int* rc = as_const(reinterpret_cast<const int*>(a.node_rects)) + 4u * (size_t)sidx * s.n_nodes;  // scalar loads where sidx is wave-uniform
         const uint32_t nn = s.n_nodes < 64u ? s.n_nodes : 64u;

@@ -637,7 +637,8 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         const int li = a.shadow_light[slot];
         const RTU_CONST RtuLight& l = as_const(s.lights)[li];
         f3 lvec = ld3(l.vec);
-        if (slot < RTU_LMASK_LIGHTS) lslot = (int)slot;
+        // (stage 2 of a scene with one masked mesh: the ray is here because that mesh's mask let it through — no second look)
+        if (slot < RTU_LMASK_LIGHTS && (DEFER || STATS || s.n_cover > 1u)) lslot = (int)slot;
         if (l.type == RTU_LIGHT_DIRECT) {
             r.dir = -lvec;
         } else if (SMPD && l.size > 0) {

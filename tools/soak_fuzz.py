@@ -34,6 +34,7 @@ rnd0 = random.Random(1)
 first, last = int(sys.argv[1]), int(sys.argv[2])
 only = [int(v) for v in os.environ.get("SOAK_SEEDS", "").split(",") if v]
 dbg = int(os.environ.get("SOAK_DBG", "0"))
+spp = int(os.environ.get("SOAK_SAMPLES", "0"))  # > 0: recipe S with that many samples per pixel (glossy bounces, soft shadows, lens); single frames and shards only
 ctx = pkg.Context(0)
 bad = []
 W, H = 157, 99
@@ -49,7 +50,7 @@ def same(a, b, what, seed):
 for seed in (only or range(first, last)):
     rnd = random.Random(1000 + seed)
     xml = d / ("s%d.xml" % seed)
-    xml.write_text(fz._scene_xml(rnd, d, seed % 3 == 2))
+    xml.write_text(fz._make_stochastic(fz._scene_xml(rnd, d, seed % 3 == 2), rnd) if spp else fz._scene_xml(rnd, d, seed % 3 == 2))
     scene = pkg.Scene.from_xml(str(xml))
     ctx.upload(scene)
     if dbg:
@@ -60,19 +61,22 @@ for seed in (only or range(first, last)):
         cam.pos[0] += 1.1 * i
         cam.fov += 7.0 * i
         cams.append(cam)
-    refs = [ctx.render(pkg.frame_setup(c, W, H, collect_stats=True), stats=True)[0] for c in cams]
+    kw = {"samples": spp} if spp else {}
+    refs = [ctx.render(pkg.frame_setup(c, W, H, collect_stats=True, **kw), stats=True)[0] for c in (cams[:1] if spp else cams)]
     ok = True
     for thr in (10 ** 9, 1):
-        fr = pkg.frame_setup(cams[0], W, H)
+        fr = pkg.frame_setup(cams[0], W, H, **kw)
         fr.coop_threshold = thr
         ok &= same(ctx.render(fr)[0], refs[0], "single frame thr %d" % thr, seed)
         shards, frames = [], []
         for r in range(3):
-            f = pkg.frame_setup(cams[0], W, H, shard_rank=r, shard_count=3)
+            f = pkg.frame_setup(cams[0], W, H, shard_rank=r, shard_count=3, **kw)
             f.coop_threshold = thr
             shards.append(ctx.render(f)[0])
             frames.append(f)
         ok &= same(pkg.assemble(shards, frames, H), refs[0], "3 shards thr %d" % thr, seed)
+        if spp:
+            continue  # (frames in flight are recipe W)
         fb = [pkg.frame_setup(c, W, H) for c in cams]
         for f in fb:
             f.coop_threshold = thr

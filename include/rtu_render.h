@@ -231,6 +231,11 @@ int  rtu_debug_walk_stack_limit(RtuContext* ctx, uint32_t entries);
  * 4-wide nodes, 8-wide nodes}. */
 int  rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5);
 
+/* Diagnostic: the occluder lists of shadow rays built at upload (rtu_device.h DevLightMask), one per (non-ambient light < 4,
+ * masked mesh node) pair that got one, in build order: out5 = {light slot, masked mesh slot, grid size G, entries of all
+ * cells together, entries of the longest cell}. RTU_ERR_ARG past the last one. */
+int  rtu_light_list_info(const RtuContext* ctx, uint32_t index, uint32_t* out5);
+
 /* Diagnostic: Shade() frames per recursion level (6 values) and rays deferred to stage 2 per phase
  * (7 values: primary, then levels 0..5) of the most recent frame (fast variant). Synchronises. */
 int  rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out);

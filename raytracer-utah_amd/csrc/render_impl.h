@@ -63,7 +63,8 @@ namespace {
 #define RTU_OCC_PRIMARY __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
 #ifndef RTU_OCC_TRACE
-#define RTU_OCC_TRACE
+// k_trace (fast variant): five wavefronts per SIMD (<= 96 VGPRs; left alone it takes 97 since the occluder-list lookups and fits four)
+#define RTU_OCC_TRACE __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 #ifndef RTU_OCC_WALK
 // the one-lane-per-ray stage-2 walks: three wavefronts per SIMD (<= 168 VGPRs; k_primary2 left alone takes 173 and fits two)
@@ -637,8 +638,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
         const int li = a.shadow_light[slot];
         const RTU_CONST RtuLight& l = as_const(s.lights)[li];
         f3 lvec = ld3(l.vec);
-        // (stage 2 of a scene with one masked mesh: the ray is here because that mesh's mask let it through — no second look)
-        if (slot < RTU_LMASK_LIGHTS && (DEFER || STATS || s.n_cover > 1u)) lslot = (int)slot;
+        if (slot < RTU_LMASK_LIGHTS) lslot = (int)slot;  // (a hard shadow ray: the light's occluder lists apply, rtu_intersect.h trace)
         if (l.type == RTU_LIGHT_DIRECT) {
             r.dir = -lvec;
         } else if (SMPD && l.size > 0) {
@@ -700,7 +700,7 @@ __device__ __forceinline__ bool frame_ray(const KernelArgs& a, int L, int sel, u
 
 // stage 1: one lane per (frame, ray slot), slot-major in chunks of 64 frames
 template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L, int sel, int ph) {
+__device__ __forceinline__ void trace_stage1(const KernelArgs& a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + ((sel & SEL_A_NEEDS_B) ? 1 : 0));
     __shared__ uint32_t s_stack[STATS ? STACK * 64 : 1];
     const LevelBuffers& lv = a.lv[L];
@@ -748,6 +748,11 @@ __global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L,
     flush_counters<STATS>(a, cnt);
     flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L);
 }
+// (two kernels around one body: the occupancy hint is the fast variant's — the counting variant keeps a traversal stack per lane)
+template <int STACK, bool STATS, int TEX>
+__global__ void __launch_bounds__(64) RTU_OCC_TRACE k_trace(KernelArgs a, int L, int sel, int ph) { trace_stage1<STACK, STATS, TEX>(a, L, sel, ph); }
+template <int STACK, int TEX>
+__global__ void __launch_bounds__(64) k_trace_counting(KernelArgs a, int L, int sel, int ph) { trace_stage1<STACK, true, TEX>(a, L, sel, ph); }
 
 // stage 2, long lists: one lane per deferred ray
 template <int STACK, int TEX>
@@ -1672,8 +1677,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const int ph = 1 + L;  // defer list of this level's tracing phase
         if (stats) {
             if constexpr (!CNTD) {
-                hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
-                if (L + 1 < levels) hipLaunchKernelGGL((k_trace<STACK, true, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
+                hipLaunchKernelGGL((k_trace_counting<STACK, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_SHADOW | SEL_MAIN | SEL_C), ph);
+                if (L + 1 < levels) hipLaunchKernelGGL((k_trace_counting<STACK, TEX>), gridT, block, 0, stream, a, L, (int)(SEL_A | SEL_A_NEEDS_B), ph);
                 hipLaunchKernelGGL((k_consume<true, TEX>), gridF, block, 0, stream, a, L);
             }
         } else {

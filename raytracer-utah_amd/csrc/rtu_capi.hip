@@ -72,6 +72,8 @@ struct RtuContext {
     hipEvent_t probe_ev[2 * kProbePairs] = {};
     struct MeshInfo { uint32_t faces, sah_depth, stack4, nodes4, nodes8; };
     std::vector<MeshInfo> mesh_info;
+    struct LightListInfo { uint32_t light, cover, G, entries, longest; };  // the occluder lists built at upload (rtu_light_list_info)
+    std::vector<LightListInfo> light_list_info;
     // cameras of a batch of frames: written into the next slot of a ring of pinned host slots, copied to d_cams on the launch
     // stream ahead of the kernels (stream order protects d_cams; an event per slot protects the slot from being rewritten
     // while its copy is still pending)
@@ -506,29 +508,42 @@ float world_bounds(const RtuSceneDesc* s, std::vector<DevNode>& nodes) {
     return (float)scale;
 }
 
-// SHADOW MASKS (DevLightMask): for each of the first RTU_LMASK_LIGHTS non-ambient lights and each masked mesh node, the mesh as
-// the light sees it. Every triangle's world-space box, widened by the cull margin (shadow rays start on the scene's surfaces:
-// |origin| <= the scene's scale), is projected corner by corner in binary64 — through a pinhole at a point light, looking at the
-// centre of the mesh; along the direction of a direct light — and the texels its rectangle touches (one texel of slack on every
-// side) are set. A mask is unusable when some corner is not in front of the pinhole (the light is inside or too close to the
-// mesh's hull) or the mesh has no extent from there. The frame, offset and scale go to the device as floats: their rounding
-// (1e-6 of the coordinates) is a few hundredths of a texel.
-int build_light_masks(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<std::vector<float4>>& tri_boxes, float wscale, DevScene& ds) {
+// OCCLUDER LISTS OF SHADOW RAYS (DevLightMask): for each of the first RTU_LMASK_LIGHTS non-ambient lights and each masked mesh
+// node, the mesh as the light sees it — through a pinhole at a point light, looking at the centre of the mesh; along the
+// direction of a direct light — on a G x G grid, and per cell the triangles that a shadow ray whose ORIGIN projects into the
+// cell can possibly touch. A triangle is entered into every cell that its projection, grown by a slack S, overlaps (exact
+// triangle / square overlap: the separating-axis test on the square's sides and the triangle's edges), where S covers
+//   * the cull margin: the ray's line, its rounded direction and the binary32 transformation chain stay within
+//     wid = 1e-4 * scene scale + 1e-5 * |coordinates| of the ideal segment origin -> light (shadow rays start on the scene's
+//     surfaces: |origin| <= the scene's scale); a displacement of wid on every axis moves a projection by at most
+//     wid * sqrt(3) * (1 + |u|) / (depth - wid * sqrt(3)) (pinhole; wid * sqrt(3) orthographic);
+//   * the device's binary32 evaluation of the cell coordinates (err: a few 1e-6 of the operands, bounded below per list;
+//     a list whose bound exceeds a quarter of a cell is not used);
+//   * a quarter of a cell on top.
+// A list is unusable when some corner of a triangle's widened box is not in front of the pinhole (the light is inside or too
+// close to the mesh's hull) or the mesh has no extent from there. G grows with the triangle count (a triangle spans a few
+// cells) up to RTU_LGRID_MAX and is halved while the lists would hold more than 32 M entries.
+struct CoverMesh {
+    std::vector<float4> boxes;      // per face: world-space box {lo} {hi}, rounded outwards
+    std::vector<double> verts;      // per face: 3 world-space vertices (9 doubles)
+    std::vector<uint32_t> slot_of;  // face -> slot in the leaf order of the mesh's fast tree
+};
+int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<CoverMesh>& cover, float wscale, DevScene& ds) {
     ds.lmask = nullptr;
     std::vector<uint32_t> lights;
     for (uint32_t i = 0; i < s->n_lights && lights.size() < RTU_LMASK_LIGHTS; i++)
         if (s->lights[i].type != RTU_LIGHT_AMBIENT) lights.push_back(i);
-    const uint32_t nc = (uint32_t)tri_boxes.size();
+    const uint32_t nc = (uint32_t)cover.size();
     if (lights.empty() || nc == 0) return RTU_OK;
     std::vector<DevLightMask> masks(lights.size() * nc);
     memset(masks.data(), 0, masks.size() * sizeof(DevLightMask));
-    const double G = (double)RTU_LMASK_G;
+    const double r3 = 1.7320508075688772;
     for (size_t j = 0; j < lights.size(); j++) {
         const RtuLight& l = s->lights[lights[j]];
         const bool point = l.type == RTU_LIGHT_POINT;
         for (uint32_t c = 0; c < nc; c++) {
             DevLightMask& m = masks[j * nc + c];
-            const std::vector<float4>& boxes = tri_boxes[c];
+            const std::vector<float4>& boxes = cover[c].boxes;
             const size_t nf = boxes.size() / 2;
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (size_t f = 0; f < nf; f++) {
@@ -552,17 +567,18 @@ int build_light_masks(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
             const double xl = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
             for (int k = 0; k < 3; k++) X[k] /= xl;
             const double Y[3] = {Z[1] * X[2] - Z[2] * X[1], Z[2] * X[0] - Z[0] * X[2], Z[0] * X[1] - Z[1] * X[0]};
-            // per triangle: the rectangle of its widened box in the light's (u, v)
-            std::vector<double> rect(nf * 4);
-            double U0 = 1e300, U1 = -1e300, V0 = 1e300, V1 = -1e300;
+            // per triangle: the rectangle of its widened box in the light's (u, v) — the extent of the grid, and the check that
+            // everything the list stands for lies in front of the pinhole
+            double U0 = 1e300, U1 = -1e300, V0 = 1e300, V1 = -1e300, ratio = 1.0;
             bool ok = true;
+            std::vector<double> wid_of(nf);
             for (size_t f = 0; f < nf && ok; f++) {
                 const float4 a = boxes[2 * f], b = boxes[2 * f + 1];
                 const double al[3] = {a.x, a.y, a.z}, bh[3] = {b.x, b.y, b.z};
                 double big = 0;
                 for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(al[k]), std::fabs(bh[k])));
                 const double wid = 1e-4 * (double)wscale + 1e-5 * big;
-                double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300;
+                wid_of[f] = wid;
                 for (int cn = 0; cn < 8; cn++) {
                     const double q[3] = {((cn & 1) ? bh[0] + wid : al[0] - wid) - L[0], ((cn & 2) ? bh[1] + wid : al[1] - wid) - L[1],
                                          ((cn & 4) ? bh[2] + wid : al[2] - wid) - L[2]};
@@ -571,34 +587,129 @@ int build_light_masks(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                         const double depth = q[0] * Z[0] + q[1] * Z[1] + q[2] * Z[2];
                         const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
                         if (!(depth > 1e-3 * len)) { ok = false; break; }  // (within 89.94 degrees of the axis: tan stays below 1000)
+                        ratio = std::max(ratio, len / depth);
                         u /= depth; v /= depth;
                     }
-                    u0 = std::min(u0, u); u1 = std::max(u1, u); v0 = std::min(v0, v); v1 = std::max(v1, v);
+                    U0 = std::min(U0, u); U1 = std::max(U1, u); V0 = std::min(V0, v); V1 = std::max(V1, v);
                 }
-                rect[4 * f] = u0; rect[4 * f + 1] = u1; rect[4 * f + 2] = v0; rect[4 * f + 3] = v1;
-                U0 = std::min(U0, u0); U1 = std::max(U1, u1); V0 = std::min(V0, v0); V1 = std::max(V1, v1);
             }
             if (!ok || !(U1 > U0) || !(V1 > V0)) continue;
             const double mag = std::max(std::max(std::fabs(U0), std::fabs(U1)), std::max(std::fabs(V0), std::fabs(V1)));
             if (!std::isfinite(mag) || (U1 - U0) < 1e-4 * mag || (V1 - V0) < 1e-4 * mag) continue;  // no extent a float lookup could resolve
-            // the grid spans the extent plus two texels on every side
-            const double du = (U1 - U0) / (G - 4), dv = (V1 - V0) / (G - 4);
-            const double gu0 = U0 - 2 * du, gv0 = V0 - 2 * dv;
-            for (size_t f = 0; f < nf; f++) {
-                int x0 = (int)std::floor((rect[4 * f] - gu0) / du) - 1, x1 = (int)std::floor((rect[4 * f + 1] - gu0) / du) + 1;
-                int y0 = (int)std::floor((rect[4 * f + 2] - gv0) / dv) - 1, y1 = (int)std::floor((rect[4 * f + 3] - gv0) / dv) + 1;
-                x0 = std::max(x0, 0); y0 = std::max(y0, 0);
-                x1 = std::min(x1, (int)RTU_LMASK_G - 1); y1 = std::min(y1, (int)RTU_LMASK_G - 1);
-                for (int y = y0; y <= y1; y++)
-                    for (int x = x0; x <= x1; x++) {
-                        const uint32_t t = (uint32_t)y * RTU_LMASK_G + (uint32_t)x;
-                        m.bits[t >> 5] |= 1u << (t & 31u);
+            // grid size: a triangle of an evenly tessellated surface spans ~ G / sqrt(nf / 2) cells; aim at six of them
+            uint32_t G = 64;
+            while (G < RTU_LGRID_MAX && (double)G < 6.0 * std::sqrt((double)nf * 0.5)) G *= 2;
+            std::vector<uint32_t> off, ent;
+            for (;; G /= 2) {
+                if (G < 16u) { ok = false; break; }
+                // the grid spans the extent plus two cells on every side
+                const double du = (U1 - U0) / ((double)G - 4), dv = (V1 - V0) / ((double)G - 4);
+                const double gu0 = U0 - 2 * du, gv0 = V0 - 2 * dv;
+                // the device's binary32 cell coordinate: (dot(p - L, X) [/ depth] - u0) * su — every operand good to a few ulp
+                const double coord = 16e-7 * ratio * (1.0 + mag);
+                const double err_cells = std::max(coord / du, coord / dv) + 4e-7 * (double)G;
+                if (!(err_cells < 0.25)) continue;  // (a coarser grid has larger cells)
+                const double S0 = 0.25 + err_cells;
+                off.assign((size_t)G * G + 1, 0u);
+                size_t total = 0;
+                bool too_many = false;
+                for (int pass = 0; pass < 2 && !too_many; pass++) {
+                    if (pass == 1) {
+                        uint32_t run = 0;
+                        for (size_t i = 0; i < (size_t)G * G; i++) { const uint32_t n = off[i]; off[i] = run; run += n; }
+                        off[(size_t)G * G] = run;
+                        ent.assign(2 * total, 0u);
                     }
+                    for (size_t f = 0; f < nf; f++) {
+                        const double* w = cover[c].verts.data() + 9 * f;
+                        double pu[3], pv[3], dmin = 1e300, umax = 0, vmax = 0;
+                        for (int k = 0; k < 3; k++) {
+                            const double q[3] = {w[3 * k] - L[0], w[3 * k + 1] - L[1], w[3 * k + 2] - L[2]};
+                            double u = q[0] * X[0] + q[1] * X[1] + q[2] * X[2], v = q[0] * Y[0] + q[1] * Y[1] + q[2] * Y[2];
+                            if (point) {
+                                const double depth = q[0] * Z[0] + q[1] * Z[1] + q[2] * Z[2];
+                                dmin = std::min(dmin, depth);
+                                u /= depth; v /= depth;
+                            }
+                            pu[k] = (u - gu0) / du; pv[k] = (v - gv0) / dv;  // in cells
+                            umax = std::max(umax, std::fabs(u)); vmax = std::max(vmax, std::fabs(v));
+                        }
+                        const double wd = wid_of[f] * r3;
+                        double Su, Sv;
+                        if (point) { Su = wd * (1.0 + umax) / (dmin - wd) / du; Sv = wd * (1.0 + vmax) / (dmin - wd) / dv; }  // (dmin > wd: the box corners passed above)
+                        else { Su = wd / du; Sv = wd / dv; }
+                        const double S = S0 + std::max(Su, Sv);
+                        const double bu0 = std::min(pu[0], std::min(pu[1], pu[2])) - S, bu1 = std::max(pu[0], std::max(pu[1], pu[2])) + S;
+                        const double bv0 = std::min(pv[0], std::min(pv[1], pv[2])) - S, bv1 = std::max(pv[0], std::max(pv[1], pv[2])) + S;
+                        int x0 = (int)std::floor(bu0), x1 = (int)std::floor(bu1), y0 = (int)std::floor(bv0), y1 = (int)std::floor(bv1);
+                        x0 = std::max(x0, 0); y0 = std::max(y0, 0);
+                        x1 = std::min(x1, (int)G - 1); y1 = std::min(y1, (int)G - 1);
+                        // the triangle's edges as separating lines: a cell (a square of half-width 0.5 + S about its centre) lies
+                        // beyond edge i when n_i . (centre - v_i) > (|n_i.x| + |n_i.y|) (0.5 + S), n_i the outward normal
+                        const double area2 = (pu[1] - pu[0]) * (pv[2] - pv[0]) - (pu[2] - pu[0]) * (pv[1] - pv[0]);
+                        const bool edges = std::fabs(area2) > 1e-9;  // (an edge-on triangle has no inside: its bounding box is all there is)
+                        double nx[3], ny[3], nd[3];
+                        for (int i = 0; i < 3; i++) {
+                            const int k = (i + 1) % 3;
+                            const double ex = pu[k] - pu[i], ey = pv[k] - pv[i];
+                            const double sg = area2 > 0 ? 1.0 : -1.0;
+                            nx[i] = sg * ey; ny[i] = -sg * ex;  // outward for a counter-clockwise triangle (area2 > 0)
+                            nd[i] = (std::fabs(nx[i]) + std::fabs(ny[i])) * (0.5 + S);
+                        }
+                        const uint32_t slot = cover[c].slot_of[f];
+                        // the depth (along Z) in front of which an origin cannot see this triangle at all — every point of it, the cull
+                        // margin and the rounding of the device's own depth included, lies beyond (entries are sorted by it)
+                        double zmin = 1e300;
+                        for (int k = 0; k < 3; k++) zmin = std::min(zmin, (w[3 * k] - L[0]) * Z[0] + (w[3 * k + 1] - L[1]) * Z[1] + (w[3 * k + 2] - L[2]) * Z[2]);
+                        zmin -= wd + 8e-6 * (r3 * (double)wscale + std::fabs(L[0]) + std::fabs(L[1]) + std::fabs(L[2]));
+                        float zf = (float)zmin;
+                        if ((double)zf > zmin) zf = std::nextafter(zf, -INFINITY);
+                        uint32_t zbits;
+                        memcpy(&zbits, &zf, 4);
+                        for (int y = y0; y <= y1; y++)
+                            for (int x = x0; x <= x1; x++) {
+                                bool out = false;
+                                if (edges)
+                                    for (int i = 0; i < 3 && !out; i++)
+                                        out = nx[i] * ((double)x + 0.5 - pu[i]) + ny[i] * ((double)y + 0.5 - pv[i]) > nd[i];
+                                if (out) continue;
+                                const size_t cell = (size_t)y * G + (size_t)x;
+                                if (pass == 0) { off[cell]++; total++; }
+                                else { const uint32_t at = off[cell]++; ent[2 * (size_t)at] = slot; ent[2 * (size_t)at + 1] = zbits; }
+                            }
+                        if (pass == 0 && total > ((size_t)32 << 20)) { too_many = true; break; }
+                    }
+                }
+                if (too_many) continue;
+                // pass 1 advanced every offset to the end of its cell: shift back
+                for (size_t i = (size_t)G * G; i > 0; i--) off[i] = off[i - 1];
+                off[0] = 0;
+                {   // nearest to the light first: a walk of the list ends at the first entry that lies beyond the ray's origin
+                    std::vector<std::pair<float, uint32_t>> tmp;
+                    for (size_t cell = 0; cell < (size_t)G * G; cell++) {
+                        const uint32_t b = off[cell], e = off[cell + 1];
+                        if (e - b < 2u) continue;
+                        tmp.clear();
+                        for (uint32_t i = b; i < e; i++) { float z; memcpy(&z, &ent[2 * (size_t)i + 1], 4); tmp.push_back({z, ent[2 * (size_t)i]}); }
+                        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b2) { return a.first < b2.first; });
+                        for (uint32_t i = b; i < e; i++) { memcpy(&ent[2 * (size_t)i + 1], &tmp[i - b].first, 4); ent[2 * (size_t)i] = tmp[i - b].second; }
+                    }
+                }
+                for (int k = 0; k < 3; k++) { m.X[k] = (float)X[k]; m.Y[k] = (float)Y[k]; m.Z[k] = (float)Z[k]; m.L[k] = (float)L[k]; }
+                m.u0 = (float)gu0; m.v0 = (float)gv0; m.su = (float)(1.0 / du); m.sv = (float)(1.0 / dv);
+                m.point = point ? 1u : 0u;
+                m.G = G;
+                break;
             }
-            for (int k = 0; k < 3; k++) { m.X[k] = (float)X[k]; m.Y[k] = (float)Y[k]; m.Z[k] = (float)Z[k]; m.L[k] = (float)L[k]; }
-            m.u0 = (float)gu0; m.v0 = (float)gv0; m.su = (float)(1.0 / du); m.sv = (float)(1.0 / dv);
-            m.point = point ? 1u : 0u;
+            if (!ok) continue;
+            int rc;
+            if ((rc = upload(ctx, off.data(), off.size(), &m.cell_off)) != RTU_OK) return rc;
+            if ((rc = upload(ctx, ent.data(), ent.size(), &m.cell_tri)) != RTU_OK) return rc;
             m.usable = 1u;
+            ctx->light_list_info.push_back({(uint32_t)j, c, m.G, (uint32_t)(ent.size() / 2), 0u});
+            uint32_t longest = 0;
+            for (size_t i = 0; i < (size_t)m.G * m.G; i++) longest = std::max(longest, off[i + 1] - off[i]);
+            ctx->light_list_info.back().longest = longest;
         }
     }
     return upload(ctx, masks.data(), masks.size(), &ds.lmask);
@@ -1225,6 +1336,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     std::vector<RtuContext::MeshInfo> mesh_info;
     std::vector<DevMesh> meshes(s->n_meshes);
     std::vector<uint32_t> fast_nodes(s->n_meshes, 0);
+    std::vector<std::vector<uint32_t>> fast_elements(s->n_meshes);  // per mesh: slot of the fast tree's leaf order -> face
     uint32_t stack_needed = 1;
     for (uint32_t mi = 0; mi < s->n_meshes; mi++) {
         const RtuMesh& m = s->meshes[mi];
@@ -1270,6 +1382,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         d.fast.bvh = nullptr;  // the kernels walk the collapsed forms (bvh4 / bvh8) of this tree
         if ((rc = upload(ctx, tri.data(), tri.size(), &d.fast.tri)) != RTU_OK) return rc;
         if ((rc = upload(ctx, sah.elements.data(), sah.elements.size(), &d.fast.elements)) != RTU_OK) return rc;
+        fast_elements[mi] = sah.elements;
         std::vector<float4> wide8;
         build_wide8(sah, sub_first, sub_total, wide8);
         if ((rc = upload(ctx, wide8.data(), wide8.size(), &d.bvh8)) != RTU_OK) return rc;
@@ -1354,7 +1467,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             if (!(std::fabs(s->lights[i].intensity[k]) < 1e15f)) ds.nol_ok = 0;
     ds.n_cover = 0;
     ctx->cover_faces = 0;
-    std::vector<std::vector<float4>> cover_host;  // per masked mesh node: the world-space boxes of its triangles
+    std::vector<CoverMesh> cover_host;  // per masked mesh node: the world-space boxes and vertices of its triangles
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++) {
         if (s->nodes[i].obj_type == RTU_OBJ_TRIMESH && ds.n_cover < RTU_MAX_COVER) {
             ds.cover_node[ds.n_cover++] = (int32_t)i;
@@ -1362,6 +1475,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             if (m.nf > ctx->cover_faces) ctx->cover_faces = m.nf;
             // world-space box of every triangle: vertices through the chain p -> tm p + pos in binary64, rounded outwards
             std::vector<float4> boxes((size_t)m.nf * 2);
+            std::vector<double> verts((size_t)m.nf * 9);
             for (uint32_t f = 0; f < m.nf; f++) {
                 double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
                 for (int v = 0; v < 3; v++) {
@@ -1373,14 +1487,20 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
                                              p[0] * t.tm[2] + p[1] * t.tm[5] + p[2] * t.tm[8] + t.pos[2]};
                         p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
                     }
-                    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+                    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); verts[9 * (size_t)f + 3 * v + k] = p[k]; }
                 }
                 boxes[2 * (size_t)f] = make_float4(std::nextafter((float)lo[0], -INFINITY), std::nextafter((float)lo[1], -INFINITY), std::nextafter((float)lo[2], -INFINITY), 0.0f);
                 boxes[2 * (size_t)f + 1] = make_float4(std::nextafter((float)hi[0], INFINITY), std::nextafter((float)hi[1], INFINITY), std::nextafter((float)hi[2], INFINITY), 0.0f);
             }
             if ((rc = upload(ctx, boxes.data(), boxes.size(), &ds.cover_box[ds.n_cover - 1])) != RTU_OK) return rc;
             ds.cover_nf[ds.n_cover - 1] = m.nf;
-            cover_host.push_back(std::move(boxes));
+            CoverMesh cm;
+            cm.boxes = std::move(boxes);
+            cm.verts = std::move(verts);
+            cm.slot_of.assign(m.nf, 0u);
+            const std::vector<uint32_t>& el = fast_elements[s->nodes[i].mesh_id];
+            for (uint32_t sl = 0; sl < (uint32_t)el.size(); sl++) cm.slot_of[el[sl]] = sl;
+            cover_host.push_back(std::move(cm));
         }
     }
     // plane nodes with a coverage mask: the corners of the node's unit square in world space (k_plane_cover)
@@ -1405,7 +1525,8 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
         memcpy(ds.pcover_quad[ds.n_pcover], quad, sizeof quad);
         ds.n_pcover++;
     }
-    if ((rc = build_light_masks(ctx, s, cover_host, wscale, ds)) != RTU_OK) return rc;
+    ctx->light_list_info.clear();
+    if ((rc = build_light_lists(ctx, s, cover_host, wscale, ds)) != RTU_OK) return rc;
     ds.obj_mask = 0;
     for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
         if (s->nodes[i].obj_type != RTU_OBJ_NONE) ds.obj_mask |= 1ull << i;
@@ -1812,6 +1933,14 @@ int rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5) {
     if (!ctx || !out5 || mesh >= ctx->mesh_info.size()) return RTU_ERR_ARG;
     const RtuContext::MeshInfo& i = ctx->mesh_info[mesh];
     out5[0] = i.faces; out5[1] = i.sah_depth; out5[2] = i.stack4; out5[3] = i.nodes4; out5[4] = i.nodes8;
+    return RTU_OK;
+}
+
+int rtu_light_list_info(const RtuContext* ctx, uint32_t index, uint32_t* out5) {
+    if (!ctx || !out5) return RTU_ERR_ARG;
+    if (index >= ctx->light_list_info.size()) return RTU_ERR_ARG;
+    const RtuContext::LightListInfo& i = ctx->light_list_info[index];
+    out5[0] = i.light; out5[1] = i.cover; out5[2] = i.G; out5[3] = i.entries; out5[4] = i.longest;
     return RTU_OK;
 }
 

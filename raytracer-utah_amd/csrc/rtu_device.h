@@ -54,6 +54,20 @@ __device__ __forceinline__ float4 gload4(GBase g, uint32_t byte_off) {
 #pragma clang diagnostic pop
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef uint32_t rtu_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 gload2u(GBase g, uint32_t byte_off) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const rtu_v2u v = *(const RTU_GLOBAL rtu_v2u*)(g.p + byte_off);
+#pragma clang diagnostic pop
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t gload1(GBase g, uint32_t byte_off) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return *(const RTU_GLOBAL uint32_t*)(g.p + byte_off);
+#pragma clang diagnostic pop
+}
 
 // One BVH over a mesh's triangles with its leaf-ordered triangle records.
 struct DevTree {
@@ -105,18 +119,21 @@ struct DevNode {                // one scene-graph node (wave-uniform data)
     float   wmin[3], wmax[3];
 };
 
-// SHADOW MASK of one (non-ambient light, mesh node) pair, made at upload (rtu_capi.hip: build_light_masks): the mesh seen from the
-// light — a point light looks at it through a pinhole at its position, a direct light along its direction — as RTU_LMASK_G x
-// RTU_LMASK_G bits: can a ray between a surface point and the light touch ANY triangle of the mesh? A shadow ray's direction
-// from the light is fixed by its origin, so one lookup with the origin answers it (trace(): the mesh is skipped when the bit is
-// clear — conservative: every triangle's world box, widened by the cull margin, one texel of slack).
-#define RTU_LMASK_G 256u
+// OCCLUDER LISTS of one (non-ambient light, mesh node) pair, made at upload (rtu_capi.hip: build_light_lists): the mesh seen from the
+// light — a point light looks at it through a pinhole at its position, a direct light along its direction — on a G x G grid of
+// cells, and for every cell the triangles whose projection (widened by the cull margin, a quarter of a cell of slack) touches it.
+// A shadow ray's direction from the light is fixed by its ORIGIN, so one lookup with the origin names every triangle of the
+// mesh the ray can possibly touch: an empty cell skips the mesh, a short list replaces the BVH walk (rtu_intersect.h:
+// mesh_shadow_cells — the reference's own triangle test on each entry; Shadow() only asks whether there is a hit).
 #define RTU_LMASK_LIGHTS 4u
+#define RTU_LGRID_MAX 1024u
 struct DevLightMask {
     float X[3], Y[3], Z[3], L[3];   // the light's frame; L: its position (point light) or 0 (direct light: orthographic along Z)
-    float u0, v0, su, sv;           // texel = ((u - u0) * su, (v - v0) * sv)
-    uint32_t usable, point, pad[2];
-    uint32_t bits[RTU_LMASK_G * RTU_LMASK_G / 32u];
+    float u0, v0, su, sv;           // cell = ((u - u0) * su, (v - v0) * sv)
+    uint32_t usable, point, G, pad;
+    const uint32_t* cell_off;       // [G * G + 1] offsets into cell_tri (cell = y * G + x)
+    const uint32_t* cell_tri;       // per entry {triangle slot (leaf order of the mesh's `fast` tree: the index of its 64-byte record), zmin (float bits):
+                                    // an origin at a smaller depth along Z cannot see the triangle}; a cell's entries in ascending zmin
 };
 
 struct DevTexture {              // RtuTexture with the image in device memory
@@ -143,7 +160,7 @@ struct DevScene {
     unsigned long long obj_mask;  // bit k: node k (< 64) carries an object
     uint32_t nol_ok, n_cover;   // n_cover: mesh nodes with a coverage mask (the first RTU_MAX_COVER of them)
     int32_t  cover_node[8];     // their node indices
-    const DevLightMask* lmask;  // [min(non-ambient lights, RTU_LMASK_LIGHTS)][n_cover] shadow masks, or nullptr
+    const DevLightMask* lmask;  // [min(non-ambient lights, RTU_LMASK_LIGHTS)][n_cover] occluder lists of shadow rays, or nullptr
     const float4* cover_box[8]; // per masked mesh node: the WORLD-space box of every triangle, 2 float4 {lo, -} {hi, -} (computed at upload in
     uint32_t cover_nf[8];       //   binary64, rounded outwards), and the triangle count   // every non-ambient light's intensity is finite and below 1e15 (make_info: lights behind the surface)
     // PLANE nodes get a coverage mask too (slots n_cover .. n_cover + n_pcover - 1 of KernelArgs::cover): a Plane is the unit square of

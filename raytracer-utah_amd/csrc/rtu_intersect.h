@@ -927,6 +927,101 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 }
 
 // ---------------------------------------------------------------------------
+// A HARD SHADOW RAY AGAINST A MESH WITHOUT A BVH WALK (DevLightMask, rtu_capi.hip build_light_lists). The ray runs from its
+// origin towards the light, so the cell of the light's grid that the ORIGIN projects into lists every triangle of the mesh the
+// ray can touch; entries [e0, e1) of the list get the reference's own triangle test (tri_hit, `t < t_max` as in a fresh
+// HitInfo of ShadowTrace, RenderFunctions.cpp:213-240). GenLight::Shadow (lightFunctions.cpp:27-37) asks only WHETHER the
+// mesh is hit, and TriObj::IntersectRay (objFunctions.cpp:333-406) says yes exactly when (a) the ray passes the mesh's own
+// box (:335-337), and (b) its walk reaches a triangle that accepts the ray. A triangle that is not in the list cannot accept
+// it (the list is conservative by the cull margin, like the boxes of the fast tree); so
+//   no entry accepts                      -> no occluder in this mesh, whatever the boxes say           (returns 0)
+//   an entry accepts, (a) fails           -> no occluder: the reference never looks at the triangles    (returns 0)
+//   an entry accepts, (a) holds, the ray passes the triangle's own bounding box with the reserve of
+//   reaches_like_the_reference            -> the reference's walk gets to that triangle: an occluder     (returns 1)
+//   otherwise                             -> ambiguous within rounding: the caller walks the reference's tree (returns 2)
+// (when the reference reaches the triangle it either accepts it or has already accepted another one: a hit both ways).
+// UNI: the light (hence the list) is the same for every lane of the wavefront — stage 1 of a tracing phase, where a wavefront
+// fires the shadow rays of ONE light: the list's base address stays in scalar registers. Stage 2 and the tail kernel mix the
+// lights of their rays: a pointer per lane.
+template <bool UNI> struct EntList;
+template <> struct EntList<true> {
+    GBase b;
+    __device__ __forceinline__ explicit EntList(const uint32_t* p) : b(global_base(p)) {}
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return gload1(b, i << 2); }
+    __device__ __forceinline__ uint2 at2(uint32_t i) const { return gload2u(b, i << 3); }
+};
+template <> struct EntList<false> {
+    const uint32_t* p;
+    __device__ __forceinline__ explicit EntList(const uint32_t* q) : p(q) {}
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ uint2 at2(uint32_t i) const { return reinterpret_cast<const uint2*>(p)[i]; }
+};
+// `depth`: the origin's depth along the light's axis (the device's own evaluation; the entries' zmin carry the margin for its
+// rounding). A cell's entries are sorted by zmin, the depth in front of which an origin cannot see the triangle: the walk ends
+// at the first entry beyond the origin — for a ray that leaves the lit side of a surface, right after the triangles around its
+// own origin. Entry i + 1's record and entry i + 2 are in flight while entry i is tested (two record buffers taking turns).
+// STEP: 1, or 8 in the cooperative kernels, where the eight lanes of a ray share the list (lane `sub` takes entries sub, sub + 8,
+// ...) and agree on the answer afterwards (any certain occluder: 1; else any ambiguous one: 2).
+template <bool FC, bool UNI, uint32_t STEP, class MeshT>
+__device__ __forceinline__ int mesh_shadow_cells(const uint32_t* cell_tri, uint32_t e0, const uint32_t e1, const float depth, const MeshT& mesh,
+                                                 const Ray& lr, float tmax, Counters& cnt, const bool fc_lane) {
+    const EntList<UNI> ents(cell_tri);
+    const GBase tris = global_base(mesh.fast.tri);
+    Hit h;
+    fresh_hit(h, tmax);
+    TriWin win;
+    win.slot = 0;
+    win.bc = mk3(0, 0, 0);
+    uint32_t found = ~0u;
+    if (STEP > 1u) e0 += threadIdx.x & (STEP - 1u);
+    // (NaN depth: no entry is "beyond", all are tested)
+    bool hasA = e0 < e1, hasB = false;
+    uint2 ea = make_uint2(0u, 0u), eb = ea;
+    TriRec A = {}, B = {};
+    if (hasA) {
+        ea = ents.at2(e0);
+        eb = ea;
+        hasA = !(__uint_as_float(ea.y) > depth);
+    }
+    if (hasA) {
+        A = load_tri(tris, ea.x);
+        if (e0 + STEP < e1) eb = ents.at2(e0 + STEP);
+        hasB = e0 + STEP < e1 && !(__uint_as_float(eb.y) > depth);
+    }
+    while (hasA) {
+        uint2 ec = eb;
+        if (hasB) {
+            B = load_tri(tris, eb.x);
+            if (e0 + 2u * STEP < e1) ec = ents.at2(e0 + 2u * STEP);
+        }
+        if (FC) { cnt.t_tri++; cnt.t_bytes += 8u; }  // (every lane tests its own entries)
+        if (tri_hit<false, false>(A, ea.x, lr, h, win, cnt) == 1) { found = ea.x; break; }
+        if (!hasB) break;
+        hasA = e0 + 2u * STEP < e1 && !(__uint_as_float(ec.y) > depth);
+        uint2 ed = ec;
+        if (hasA) {
+            A = load_tri(tris, ec.x);
+            if (e0 + 3u * STEP < e1) ed = ents.at2(e0 + 3u * STEP);
+        }
+        if (FC) { cnt.t_tri++; cnt.t_bytes += 8u; }
+        if (tri_hit<false, false>(B, eb.x, lr, h, win, cnt) == 1) { found = eb.x; break; }
+        ea = ec;
+        eb = ed;
+        hasB = hasA && e0 + 3u * STEP < e1 && !(__uint_as_float(ed.y) > depth);
+        e0 += 2u * STEP;
+    }
+    int code = 0;
+    if (found != ~0u && box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT))
+        code = reaches_like_the_reference(mesh.v, mesh.f + 3 * mesh.fast.elements[found], lr, mesh.scale) ? 1 : 2;
+    if (STEP > 1u) {  // the group's answer (all lanes of a group are here: they share the ray and the list)
+        const uint32_t sh = threadIdx.x & 63u & ~(STEP - 1u);
+        const uint32_t c1 = (uint32_t)(__ballot(code == 1) >> sh) & ((1u << STEP) - 1u), c2 = (uint32_t)(__ballot(code == 2) >> sh) & ((1u << STEP) - 1u);
+        code = c1 ? 1 : c2 ? 2 : 0;
+    }
+    return code;
+}
+
+// ---------------------------------------------------------------------------
 // Trace / ShadowTrace (RenderFunctions.cpp:181-240), recursion over the node tree
 // flattened to a pre-order loop. Only h.z (and h.front in the sphere quirk) feeds
 // later intersection tests, so FromNodeCoords is applied once, after the loop, to the final
@@ -952,7 +1047,7 @@ __device__ __forceinline__ bool mesh_hit_coop(const MeshT& mesh, const Ray& ray,
 // and exact test. (The margin is 100 x the slab rounding; the bound of a sphere is widened further at upload by what the
 // cancellation in its discriminant can move a grazing root, rtu_capi.hip world_bounds.) `skip` marks nodes the caller
 // has already excluded in the same sense: for primary rays, pixels outside the node's screen rectangle (k_node_rects).
-template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false>
+template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false, bool ULS = DEFER>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
                                       const uint32_t stride = 64, const float4* lds_nodes = nullptr, const unsigned long long skip = 0,
                                       const bool rays_bounded = false, const int lslot = -1) {
@@ -976,33 +1071,56 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         if (shadow && any) continue;  // ShadowTrace returns at the first occluder (:223-225)
         if (DEFER && deferred) continue;
         if (CULL && k < 64u && ((skip >> k) & 1ull)) continue;
+        // a hard shadow ray towards light `lslot` (lslot < RTU_LMASK_LIGHTS) and a mesh node with an occluder list for that light: the
+        // cell of the ray's ORIGIN names the triangles the ray can touch — none: the mesh is skipped; else they are tested below
+        uint32_t le0 = 0, le1 = 0;  // le1 > le0: the entries
+        const uint32_t* ltri = nullptr;
+        float ldepth = 0.0f;
+        int lc = -1;
         if (CULL && lslot >= 0 && n.obj_type == RTU_OBJ_TRIMESH && s.lmask && s.node_bounds) {
-            // a shadow ray towards light `lslot` (lslot < RTU_LMASK_LIGHTS): the light's mask of this mesh, looked up with the ray's origin
             int c = -1;
             for (uint32_t i = 0; i < s.n_cover; i++) c = s.cover_node[i] == (int)k ? (int)i : c;
             if (c >= 0) {
-                const RTU_CONST DevLightMask& m = as_const(s.lmask)[(uint32_t)lslot * s.n_cover + (uint32_t)c];
+                // (ULS: the light is wave-uniform, the list's frame arrives by scalar loads; else by one load per lane)
+                const DevLightMask& mg = s.lmask[(uint32_t)lslot * s.n_cover + (uint32_t)c];
+                const RTU_CONST DevLightMask& mc = as_const(s.lmask)[(uint32_t)(ULS ? __builtin_amdgcn_readfirstlane(lslot) : 0) * s.n_cover + (uint32_t)c];
+                DevLightMask m;
+                if (ULS) {
+                    for (int q = 0; q < 3; q++) { m.X[q] = mc.X[q]; m.Y[q] = mc.Y[q]; m.Z[q] = mc.Z[q]; m.L[q] = mc.L[q]; }
+                    m.u0 = mc.u0; m.v0 = mc.v0; m.su = mc.su; m.sv = mc.sv; m.usable = mc.usable; m.point = mc.point; m.G = mc.G;
+                    m.cell_off = mc.cell_off; m.cell_tri = mc.cell_tri;
+                } else {
+                    m = mg;
+                }
                 if (m.usable) {
                     const f3 v = wr.p - ld3(m.L);
                     float u = dot3(v, ld3(m.X)), w = dot3(v, ld3(m.Y));
-                    bool covered = true;
+                    bool covered = true, listed = false;
+                    const float depth = dot3(v, ld3(m.Z));
+                    ldepth = depth;
                     if (m.point) {
-                        const float depth = dot3(v, ld3(m.Z));
                         const float rd = __builtin_amdgcn_rcpf(depth);
                         u *= rd; w *= rd;
                         if (!(depth > 0.0f)) covered = false;  // the origin is on the far side of the light: the mesh is not between them
                     }
                     const float tu = (u - m.u0) * m.su, tw = (w - m.v0) * m.sv;
+                    const float G = (float)m.G;
                     if (covered) {
-                        if (!(tu >= 0.0f && tw >= 0.0f && tu < (float)RTU_LMASK_G && tw < (float)RTU_LMASK_G)) covered = tu != tu || tw != tw;  // outside the mesh's extent (NaN: no answer)
+                        if (!(tu >= 0.0f && tw >= 0.0f && tu < G && tw < G)) covered = tu != tu || tw != tw;  // outside the mesh's extent (NaN: no answer)
                         else {
-                            const uint32_t texel = (uint32_t)tw * RTU_LMASK_G + (uint32_t)tu;
-                            covered = ((s.lmask[(uint32_t)lslot * s.n_cover + (uint32_t)c].bits[texel >> 5] >> (texel & 31u)) & 1u) != 0;
+                            const uint32_t cell = (uint32_t)tw * m.G + (uint32_t)tu;
+                            const EntList<ULS> offs(m.cell_off);
+                            le0 = offs.at(cell);
+                            le1 = offs.at(cell + 1u);
+                            ltri = m.cell_tri;
+                            covered = le1 > le0;
+                            listed = true;
                         }
                     }
-                    RTU_TOUCH_WAVE(t_bytes, 64u);  // the mask's frame (scalar loads)
-                    RTU_TOUCH(t_bytes, 4u);        // ... and the lane's word of it
+                    RTU_TOUCH_WAVE(t_bytes, 64u);  // the list's frame (scalar loads)
+                    RTU_TOUCH(t_bytes, 8u);        // ... and the lane's cell of it
                     if (!covered) continue;
+                    if (listed) lc = c;
                 }
             }
         }
@@ -1032,7 +1150,21 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
         bool hit;
         if (n.obj_type == RTU_OBJ_SPHERE) hit = sphere_hit(lr, h, TEX);
         else if (n.obj_type == RTU_OBJ_PLANE) hit = plane_hit(lr, h, TEX);
-        else if (DEFER) {
+        else if (lc >= 0 && !(s.dbg & 64u)) {
+            // (rtu_debug_flags bit 6: the occluder lists only say "empty cell or not", every listed ray walks the tree)
+            const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
+            // stage 1 only looks the cell up: a ray with entries to test joins the defer list, where stage 2 finds it among rays
+            // that all have a list to walk (inline, a fifth of a wavefront's rays walked theirs while the others waited, and the
+            // kernel's registers cost it two of its five wavefronts per SIMD: measured, no faster than this and 10 % slower alone)
+            const int code = DEFER ? 2 : mesh_shadow_cells<FC, ULS, COOP ? 8u : 1u>(ltri, le0, le1, ldepth, mesh, lr, h.z, cnt, fc_lane);
+            hit = code == 1;
+            if (code == 2) {  // within rounding of a bounding box: the reference's own walk decides
+                if (DEFER) deferred = true;
+                else if (COOP) hit = box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT) &&
+                                     mesh_hit_coop<STACK, CULL, FC>(mesh, lr, shadow, h, stk, cnt, stride, lds_nodes, s.walk_stack_limit);
+                else hit = mesh_hit<STACK, STATS, CULL, FC>(mesh, lr, shadow, h, stk, cnt, s.walk_stack_limit);
+            }
+        } else if (DEFER) {
             const RTU_CONST DevMesh& mesh = meshes[n.mesh_id];
             if (box_hit(lr, ld3(mesh.bmin), ld3(mesh.bmax), RTU_BIGFLOAT)) deferred = true;
             hit = false;

@@ -19,8 +19,16 @@ DOMINANT one (longest per launch, found by an untimed probe of every kernel slot
 counted by the fast variant itself (collect_stats == 2: the very kernels that are timed, counting what
 they read and write — include/rtu_render.h RtuTouched) divided by its duration, measured with HIP events
 around its launches INSIDE the timed region. `roofline.kernels` lists every kernel of the sequence the
-same way. frac is against the HBM peak (8 TB/s); the scene is cache-resident, so `l2_frac` (34.5 TB/s)
-is given beside it.
+same way. `achieved` / `frac` are SURVEY 8d's nominal figure: cache-agnostic touched bytes against the HBM
+peak (from the device's own memory clock and bus width, rtu_device_info; the guide's 8 TB/s as a fall-back).
+The scene is cache-resident, so that figure says how fast a kernel goes through its working set, NOT what
+binds it: `bound` and `hbm_counter_frac` / `valu_issue_frac` / `lanes_active` come from the committed
+rocprofv3 PMC profile of the same command (profiles/rNN_per_kernel.json, labelled profile-derived, like
+`traffic`), and `l2_frac` (34.5 TB/s) is given beside them.
+
+Timing: the K-step region (exactly --steps frames, barrier + synchronize on both sides) is run `--repeats` R
+times back to back (default 50: the driver's --steps 20 is ONE 1.4 ms launch sequence, far too short a
+sample on its own); `value` and `ms_per_step` are the MEDIAN region's, config.repeats has min / max / first.
 
 N=1: python bench.py.  N>1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by
 interleaved 8-row bands (band b -> rank b % N, scene replicated, no data-path collective) and every batch
@@ -42,8 +50,33 @@ sys.path.insert(0, REPO)
 
 WORKLOAD_TAG = "teapot2_1080"
 WORKLOAD_NAME = "SceneFiles/Teapot/scene2.xml @1920x1080, recipe W (1 spp, Shade depth 5)"
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec) — the fall-back of hbm_peak()
 L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s
+
+
+def hbm_peak(pkg, device):
+    """(GB/s, where the figure comes from): the device's own memory clock x bus width, double data rate ("confirm on
+    the machine, do not hard-code"); the guide's constant when the machine reports something implausible for an MI355X."""
+    try:
+        info = pkg.device_info(device)
+        gbs = 2.0 * info["memory_clock_khz"] * 1e3 * info["memory_bus_bits"] / 8 / 1e9
+        src = "hipGetDeviceProperties: memoryClockRate %d kHz x memoryBusWidth %d bit x 2 (DDR)" % (info["memory_clock_khz"], info["memory_bus_bits"])
+        if 4000.0 <= gbs <= 12000.0:
+            return gbs, src
+        return HBM_PEAK_GBS, "MI355X_MICROARCH.md (8 TB/s): the device reports %s = %.0f GB/s, implausible for HBM3E x 8 stacks" % (src, gbs)
+    except Exception as e:  # noqa: BLE001 — a diagnostic must not take the bench down
+        return HBM_PEAK_GBS, "MI355X_MICROARCH.md (8 TB/s): rtu_device_info failed (%s)" % e
+
+
+def kernel_profile():
+    """The newest committed per-kernel PMC summary (tools/profile_summary.py), or {}."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_per_kernel.json")))
+    if not files:
+        return {}
+    prof = json.load(open(files[-1]))
+    prof["file"] = os.path.relpath(files[-1], REPO)
+    return prof
 ORBIT_STEP_DEG = 2.0
 
 
@@ -72,6 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--repeats", type=int, default=50,
+                    help="the timed K-step region is run this many times back to back; value / ms_per_step are the median region's (min, max and the first in config.repeats)")
     ap.add_argument("--tag", default=WORKLOAD_TAG, help="golden tag to render (default: the headline workload)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (0 = every core this process may use: its affinity mask, capped by the cgroup CPU quota)")
@@ -295,34 +330,45 @@ def main():
             kernels[name]["ms"] = ms / max(n, 1)
         ctx.probe_kernel(None)
         dominant = max(kernels, key=lambda k: kernels[k]["ms"])
-        ctx.probe_kernel(dominant)  # from here on its launches are bracketed by HIP events (at most 64 are kept)
 
     batches = [min(B, args.steps - i) for i in range(0, args.steps, B)]  # EXACTLY args.steps frames
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for j, nb in enumerate(batches):
-        if dominant and nb != batches[0]:
-            ctx.probe_kernel(None)  # the probe averages full batches only (a host-side flag: nothing is queued)
-        step(j, nb, events[j])
-    finish()
-    if pipe:
-        pipe.drain()  # every frame of the timed region rendered AND gathered
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    R = max(1, args.repeats if not sampled else min(args.repeats, 3))
+    region_s, seq_ms, dom_sum, dom_n = [], [], 0.0, 0
+    for rep in range(R):
+        # one timed region: exactly args.steps frames, barrier + synchronize on both sides
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in batches]
+        if dominant:
+            ctx.probe_kernel(dominant)  # its launches are bracketed by HIP events (at most 64 are kept per read)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j, nb in enumerate(batches):
+            if dominant and nb != batches[0]:
+                ctx.probe_kernel(None)  # the probe averages full batches only (a host-side flag: nothing is queued)
+            step(j, nb, events[j])
+        finish()
+        if pipe:
+            pipe.drain()  # every frame of the timed region rendered AND gathered
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        region_s.append(time.perf_counter() - t0)
+        if dominant:
+            ms, n = ctx.probe_read()
+            dom_sum += ms
+            dom_n += n
+            ctx.probe_kernel(None)
+        # HIP events on the launch stream, around the full launch sequences (B frames each; a shorter last batch is left out)
+        seq_ms += [a.elapsed_time(b) for (a, b), nb in zip(events, batches) if nb == batches[0]]
+    if dist:  # every rank's regions -> the slowest rank's time of each region (the barrier makes them nearly equal anyway)
+        tr = torch.tensor(region_s, dtype=torch.float64, device=cdev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        region_s = [float(v) for v in tr.tolist()]
+    elapsed = float(np.median(region_s))
     gathered = pipe.last_gathered() if pipe else None
-    dom_ms = None
-    if dominant:
-        ms, n = ctx.probe_read()
-        dom_ms = ms / max(n, 1)
-        ctx.probe_kernel(None)
-    # HIP events on the launch stream, around the full launch sequences (B frames each; a shorter last batch is left out)
-    full = [(a.elapsed_time(b), nb) for (a, b), nb in zip(events, batches) if nb == batches[0]]
-    kernel_ms = float(np.mean([t for t, _ in full]))
+    dom_ms = dom_sum / max(dom_n, 1) if dominant else None
+    kernel_ms = float(np.mean(seq_ms))
     ctx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
     rays_total = sum(rays_of[j] for nb in batches for j in range(nb))
 
@@ -330,9 +376,6 @@ def main():
     dom_bytes = float(kernels[dominant]["bytes"]) if dominant else 0.0
     t = torch.tensor([elapsed, kernel_ms, seq_bytes, dom_ms or 0.0, dom_bytes], dtype=torch.float64, device=cdev)
     if dist:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
         # the roofline is the slowest rank's
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -382,34 +425,45 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        peak, peak_src = hbm_peak(pkg, local_rank)
+        roof = {"bound": "unprofiled", "achieved": None, "peak": round(peak, 1), "unit": "GB/s", "frac": None, "traffic": None, "peak_source": peak_src}
         if dominant:
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
             kname = dominant
-            prof = {}
-            tfile = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
-            if world == 1 and args.tag == WORKLOAD_TAG and os.path.exists(tfile):
-                prof = json.load(open(tfile))
-            traffic = (prof.get("per_kernel", {}).get(kname) or {}).get("hbm_bytes_per_launch")
-            if traffic and prof.get("frames_in_flight") and prof["frames_in_flight"] != batches[0]:
-                traffic = int(traffic * batches[0] / prof["frames_in_flight"])  # profiled at another batch size: per frame in flight, times this run's
-            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            # what the committed PMC profile of this command says about the dominant kernel (profile-derived, not measured in this run)
+            prof = kernel_profile() if (world == 1 and args.tag == WORKLOAD_TAG) else {}
+            pk = (prof.get("per_kernel", {}).get(kname) or {})
+            scale = batches[0] / prof["frames_in_flight"] if prof.get("frames_in_flight") else 1.0  # profiled at another batch size: per frame in flight
+            traffic = int(pk["hbm_bytes_per_launch"] * scale) if pk.get("hbm_bytes_per_launch") else None
+            hbm_cf = round(pk["hbm_bytes_per_launch"] / (pk["us"] * 1e-6) / 1e9 / peak, 4) if pk.get("hbm_bytes_per_launch") and pk.get("us") else None
+            bound = "unprofiled"
+            if hbm_cf is not None:
+                # the PMC counters decide the label: a kernel that moves less than half of what HBM could in its time is not HBM-bound
+                bound = "hbm" if hbm_cf >= 0.5 else "valu-issue/divergence (working set cache-resident: lanes_active, valu_issue_frac)"
+            roof = {"bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "GB/s", "frac": round(achieved / peak, 5),
+                    "frac_is": "SURVEY 8d's nominal figure: cache-agnostic touched bytes / kernel time / HBM peak — how fast the kernel goes through its working "
+                               "set, which is cache-resident; what binds the kernel is in bound / hbm_counter_frac / valu_issue_frac / lanes_active",
+                    "peak_source": peak_src,
                     "traffic": traffic,
-                    "traffic_source": ("profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py at commit %s with %s frames in flight "
-                                       "(scaled to this run's %d), not measured in this run" % (prof.get("commit", "?"), prof.get("frames_in_flight"), batches[0])) if traffic else None,
-                    "kernel": kname, "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
+                    "hbm_counter_frac": hbm_cf, "valu_issue_frac": pk.get("valu_issue_frac"), "lanes_active": pk.get("lanes_active"),
+                    "waves_waiting_frac": pk.get("waiting_frac"),
+                    "profile_source": ("%s: rocprofv3 --kernel-trace --pmc passes of `%s` at commit %s with %s frames in flight (traffic scaled to this run's %d); "
+                                       "profile-derived, not measured in this run" % (prof.get("file"), prof.get("command", "bench.py"), prof.get("commit", "?"),
+                                                                                       prof.get("frames_in_flight"), batches[0])) if pk else None,
+                    "kernel": kname, "kernel_ms": round(dom_ms, 4), "kernel_launches_timed": dom_n, "algorithmic_bytes_per_launch": int(dom_bytes),
                     "l2_peak": L2_PEAK_GBS, "l2_frac": round(achieved / L2_PEAK_GBS, 5),
                     "bytes_are": "touched by the timed (fast) kernels themselves, counted per kernel by collect_stats=2 (rtu_render.h RtuTouched)",
                     "sequence": {"kernels": len(kernels), "ms": round(kernel_ms, 4), "algorithmic_bytes": int(seq_bytes),
                                  "achieved": round(seq_bytes / (kernel_ms * 1e-3) / 1e9, 2),
-                                 "frac": round(seq_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                 "frac": round(seq_bytes / (kernel_ms * 1e-3) / 1e9 / peak, 5)},
                     "kernels": {k: {"ms": round(v["ms"], 4), "bytes": v["bytes"], "rays": v["rays"],
                                     "GBps": round(v["bytes"] / max(v["ms"], 1e-6) / 1e6, 1)} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}}
-            if achieved > HBM_PEAK_GBS:  # touched bytes served from cache faster than HBM could: say so instead of printing a "fraction" > 1
+            if achieved > peak:  # touched bytes served from cache faster than HBM could: say so instead of printing a "fraction" > 1
                 roof["exceeds_hbm_peak"] = True
                 print("roofline: %.0f GB/s of touched bytes exceeds the HBM peak — the dominant kernel is cache-bound, read l2_frac" % achieved, file=sys.stderr)
         out = {
-            "metric": "Mrays/sec at 1920x1080 (primary + secondary + shadow rays per frame / frame time)",
+            "metric": "Mrays/sec at 1920x1080 (the reference's primary + secondary + shadow rays of the frames rendered / wall time; batched throughput: "
+                      "config.frames_in_flight frames with their own cameras per launch sequence — one frame alone: config.single_frame)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "the reference's own scene (flattened blob tests/golden/%s), no synthetic inputs" % args.tag,
@@ -421,7 +475,11 @@ def main():
                        "frames_in_flight": batches[0],
                        "cameras": "one per frame of a batch: the scene's camera orbited by %g degrees per frame (frame 0 = the golden camera)" % ORBIT_STEP_DEG
                                   if len(set(rays_of)) > 1 or not (args.same_camera or sampled) else "the scene's camera for every frame",
-                       "frame_latency_ms": round(kernel_ms, 4),
+                       "batch_latency_ms": round(kernel_ms, 4),  # HIP-event time of ONE launch sequence of frames_in_flight frames
+                       "repeats": {"n": R, "region_ms_median": round(elapsed * 1e3, 4), "region_ms_min": round(min(region_s) * 1e3, 4),
+                                   "region_ms_max": round(max(region_s) * 1e3, 4), "region_ms_first": round(region_s[0] * 1e3, 4),
+                                   "timed_ms_total": round(sum(region_s) * 1e3, 2),
+                                   "is": "the K-step region (exactly `steps` frames, barrier + synchronize on both sides) run n times back to back; value and ms_per_step are the median region's"},
                        "single_frame": single,
                        "sharding": ("interleaved 8-row bands, RCCL gather of the %s to rank 0, overlapped with the next batch" % (
                            "two output images (Color24 + z-image byte, 4 B per pixel, made on the device after one all-reduce of the frames' zmin / zmax)" if out4

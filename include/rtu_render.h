@@ -43,6 +43,7 @@ extern "C" {
 #define RTU_ERR_NO_SCENE    (-5)  /* render before rtu_upload_scene */
 #define RTU_ERR_NO_DEVICE   (-6)  /* no such GPU */
 #define RTU_ERR_CAPACITY    (-7)  /* more Shade() frames than provisioned (see rtu_frame_status) */
+#define RTU_ERR_CANCELLED   (-8)  /* the caller's cancel flag was raised (rtu_set_cancel_flag, RtuProgress): StopRender(), main.cpp:70-72 */
 
 #define RTU_BAND_ROWS 8  /* image rows per band; one wavefront renders an 8x8 pixel tile */
 
@@ -109,6 +110,16 @@ typedef struct RtuStats {
 int         rtu_device_count(void);
 const char* rtu_error_string(int err);
 
+/* What the machine says about GPU `device_id` (hipGetDeviceProperties): bench.py derives the HBM peak of its roofline from the
+ * memory clock and bus width reported here ("confirm on the machine, do not hard-code") and falls back to the
+ * constant of the microarchitecture guide when the figures are implausible. Needs no context. */
+typedef struct RtuDeviceInfo {
+    int32_t  compute_units, clock_khz, memory_clock_khz, memory_bus_bits;
+    uint64_t l2_bytes, hbm_bytes;
+    char     name[64], arch[64];
+} RtuDeviceInfo;
+int         rtu_device_info(int device_id, RtuDeviceInfo* out);
+
 RtuContext* rtu_create_context(int device_id, int* err_out);
 void        rtu_destroy_context(RtuContext* ctx);
 const char* rtu_last_error(const RtuContext* ctx);
@@ -136,7 +147,11 @@ int  rtu_shard_global_row(const RtuFrameDesc* frame, int local_row);
 /* Render this context's shard into DEVICE memory d_rgbz (rtu_shard_rows * width
  * float4, 16-byte aligned), asynchronously on hip_stream (a hipStream_t passed
  * as void*; NULL = the device's default stream, as in HIP itself). Inputs are already resident in
- * HBM; nothing is copied. */
+ * HBM; nothing is copied.
+ * ONE STREAM PER CONTEXT between two rtu_frame_status calls: the context's frame records, append counters, camera table,
+ * coverage masks and tile-occupancy words are shared by every launch sequence queued on it, and only stream order keeps
+ * one sequence's kernels from another's. A caller that wants two sequences in flight on two streams uses two contexts
+ * (bench.py and rtu_multi_render_frame do); switching streams after rtu_frame_status (which waits for the device) is fine. */
 int  rtu_render_frame_device(RtuContext* ctx, const RtuFrameDesc* frame, void* d_rgbz, void* hip_stream);
 
 /* Frames in flight: n_frames (<= RTU_MAX_FRAMES_IN_FLIGHT, and at most 2^26 pixels together) frames of recipe W of the uploaded scene — the same resolution, shard and
@@ -183,6 +198,43 @@ int  rtu_render_frame(RtuContext* ctx, const RtuFrameDesc* frame, float* h_rgbz,
  * rtu_render_frame(s)_device calls with different cameras and checks once learns that SOME frame of them is
  * incomplete and renders them again. */
 int  rtu_frame_status(RtuContext* ctx);
+
+/* Cancellation (StopRender(), main.cpp:70-72): a word the caller may set non-zero at any time; the context reads it between the
+ * launch sequences of a sampled frame (recipes S / P: one sequence per batch of samples — a 64-sample 1080p frame is hundreds
+ * of milliseconds) and returns RTU_ERR_CANCELLED from the render call. NULL: none. A single launch sequence (a frame of
+ * recipe W, a batch of frames in flight) is a fraction of a millisecond and is never interrupted. */
+int  rtu_set_cancel_flag(RtuContext* ctx, const volatile int* flag);
+
+/* ---- Several GPUs behind one handle (raytracer-utah_amd/csrc/rtu_multi.hip) ----------------------------------------------
+ * What SpawnRenderThreads does with CPU workers (main.cpp:29-64): fan one frame out, wait, hand back one image. The frame is
+ * sharded by interleaved RTU_BAND_ROWS-row bands (band b -> the b mod n-th device), the scene replicated on every GPU; the
+ * float4 shards are gathered to the first GPU with one grouped RCCL send / receive over xGMI (n distinct GPUs, librccl.so
+ * found) or by concurrent asynchronous copies into pinned host memory (several contexts on one GPU, or no RCCL), and land,
+ * de-interleaved, in h_rgbz = height * width float4 in image order. device_ids may repeat (n contexts on one GPU: how the
+ * one-GPU test box exercises this path). The RCCL branch with n > 1 distinct GPUs has not run on hardware.
+ *
+ * progress (may be NULL): `cancel` as rtu_set_cancel_flag (polled between sample batches on every GPU, between capacity
+ * rounds and between the shards as they are handed over); rows_done(user, rows, row0, nrows) is called once per band as
+ * the shards arrive, from the calling thread, with `rows` = nrows * width float4 of image rows [row0, row0 + nrows) — what
+ * RenderImage::IncrementNumRenderPixel (scene.h:585-588) counts and the viewport polls (viewport.cpp:390-410). h_rgbz may be
+ * NULL when rows_done consumes the rows. frame->shard_rank / shard_count are ignored. Synchronous; 0 or a negative RTU_ERR_*
+ * (rtu_multi_last_error). */
+typedef struct RtuMultiContext RtuMultiContext;
+typedef struct RtuProgress {
+    const volatile int* cancel;
+    void (*rows_done)(void* user, const float* rows, int row0, int nrows);
+    void* user;
+} RtuProgress;
+RtuMultiContext* rtu_create_context_multi(const int* device_ids, int n_devices, int* err_out);
+void        rtu_destroy_context_multi(RtuMultiContext* m);
+int         rtu_multi_size(const RtuMultiContext* m);
+RtuContext* rtu_multi_context(RtuMultiContext* m, int i);            /* the i-th GPU's context (diagnostics, rtu_debug_*) */
+const char* rtu_multi_last_error(const RtuMultiContext* m);
+int         rtu_multi_upload_scene(RtuMultiContext* m, const RtuSceneDesc* scene);
+int         rtu_multi_render_frame(RtuMultiContext* m, const RtuFrameDesc* frame, float* h_rgbz, const RtuProgress* progress);
+/* How the shards of the last rtu_multi_render_frame reached the host: 1 one context; 2 several contexts, asynchronous copies into
+ * one pinned buffer, all in flight together; 3 RCCL (grouped ncclSend / ncclRecv to the first GPU, then one copy). */
+int         rtu_multi_gather_kind(const RtuMultiContext* m);
 
 /* Diagnostic: render one frame with every wavefront stamping the GPU's constant clock on entry
  * and exit, and return, per kernel launch that ran, its slot (0 primary, 1/2 primary stage 2

@@ -32,6 +32,7 @@ RTU_ERR_STOCHASTIC = -4
 RTU_ERR_NO_SCENE = -5
 RTU_ERR_NO_DEVICE = -6
 RTU_ERR_CAPACITY = -7
+RTU_ERR_CANCELLED = -8
 
 
 class RtuError(RuntimeError):
@@ -142,7 +143,8 @@ def _sig(lib, name, restype, *argtypes):
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
                "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
-               "rtu_device_free", "rtu_copy_to_host"]
+               "rtu_device_free", "rtu_copy_to_host", "rtu_device_info", "rtu_set_cancel_flag", "rtu_create_context_multi", "rtu_destroy_context_multi",
+               "rtu_multi_size", "rtu_multi_context", "rtu_multi_last_error", "rtu_multi_upload_scene", "rtu_multi_render_frame", "rtu_multi_gather_kind"]
 _sig(hip, "rtu_device_count", _I)
 _sig(hip, "rtu_error_string", ctypes.c_char_p, _I)
 _sig(hip, "rtu_create_context", _P, _I, ctypes.POINTER(_I))
@@ -183,6 +185,40 @@ _sig(hip, "rtu_selftest_division", _I, _P, ctypes.c_ulonglong, ctypes.c_ulonglon
 _sig(hip, "rtu_device_alloc", _P, _P, ctypes.c_size_t)
 _sig(hip, "rtu_device_free", None, _P, _P)
 _sig(hip, "rtu_copy_to_host", _I, _P, _P, _P, ctypes.c_size_t)
+
+
+class RtuDeviceInfo(ctypes.Structure):
+    _fields_ = [("compute_units", ctypes.c_int32), ("clock_khz", ctypes.c_int32), ("memory_clock_khz", ctypes.c_int32), ("memory_bus_bits", ctypes.c_int32),
+                ("l2_bytes", ctypes.c_uint64), ("hbm_bytes", ctypes.c_uint64), ("name", ctypes.c_char * 64), ("arch", ctypes.c_char * 64)]
+
+
+ROWS_DONE = ctypes.CFUNCTYPE(None, _P, ctypes.POINTER(ctypes.c_float), _I, _I)
+
+
+class RtuProgress(ctypes.Structure):
+    _fields_ = [("cancel", ctypes.POINTER(_I)), ("rows_done", ROWS_DONE), ("user", _P)]
+
+
+_sig(hip, "rtu_device_info", _I, _I, ctypes.POINTER(RtuDeviceInfo))
+_sig(hip, "rtu_set_cancel_flag", _I, _P, ctypes.POINTER(_I))
+_sig(hip, "rtu_create_context_multi", _P, ctypes.POINTER(_I), _I, ctypes.POINTER(_I))
+_sig(hip, "rtu_destroy_context_multi", None, _P)
+_sig(hip, "rtu_multi_size", _I, _P)
+_sig(hip, "rtu_multi_context", _P, _P, _I)
+_sig(hip, "rtu_multi_last_error", ctypes.c_char_p, _P)
+_sig(hip, "rtu_multi_upload_scene", _I, _P, _P)
+_sig(hip, "rtu_multi_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuProgress))
+_sig(hip, "rtu_multi_gather_kind", _I, _P)
+
+
+def device_info(device_id=0):
+    """What hipGetDeviceProperties says about a GPU (dict), e.g. for the HBM peak of the roofline."""
+    o = RtuDeviceInfo()
+    rc = hip.rtu_device_info(device_id, ctypes.byref(o))
+    if rc != RTU_OK:
+        raise RtuError(rc, "rtu_device_info")
+    return {"compute_units": o.compute_units, "clock_khz": o.clock_khz, "memory_clock_khz": o.memory_clock_khz, "memory_bus_bits": o.memory_bus_bits,
+            "l2_bytes": o.l2_bytes, "hbm_bytes": o.hbm_bytes, "name": o.name.decode(), "arch": o.arch.decode()}
 
 # ---- rtu_host.h --------------------------------------------------------------
 HOST_SYMBOLS = ["rtu_scene_load_xml", "rtu_scene_clone", "rtu_scene_load_blob", "rtu_scene_load_blob_file",
@@ -296,6 +332,55 @@ def frame_setup(camera, width, height, shard_rank=0, shard_count=1, collect_stat
     f.samples = samples  # 0: recipe W; S >= 1: recipe S (soft shadows, glossy bounces, depth of field)
     f.gather_bounces = gather_bounces  # 4 (with samples): recipe P, + the Monte-Carlo gather of config 5
     return f
+
+
+class MultiContext:
+    """Several GPUs behind one handle (RtuMultiContext*): the frame sharded by interleaved 8-row bands, gathered and de-interleaved
+    under the C-ABI. device_ids may repeat (several contexts on one GPU)."""
+
+    def __init__(self, device_ids):
+        err = _I(0)
+        arr = (_I * len(device_ids))(*device_ids)
+        self._h = hip.rtu_create_context_multi(arr, len(device_ids), ctypes.byref(err))
+        if not self._h:
+            raise RtuError(err.value, hip.rtu_error_string(err.value).decode())
+        self.n = len(device_ids)
+
+    def _check(self, rc):
+        if rc != RTU_OK:
+            raise RtuError(rc, hip.rtu_multi_last_error(self._h).decode())
+
+    def upload(self, scene):
+        self._check(hip.rtu_multi_upload_scene(self._h, scene.desc_ptr))
+
+    def context_handle(self, i):
+        return hip.rtu_multi_context(self._h, i)
+
+    def render(self, frame, on_rows=None, cancel=None):
+        """The whole frame [H, W, 4] float32. on_rows(row0, nrows): called per band as the shards arrive; cancel: a ctypes.c_int the
+        caller may set non-zero (the call then raises RtuError(RTU_ERR_CANCELLED))."""
+        import numpy as np
+        out = np.empty((frame.height, frame.width, 4), np.float32)
+        prog = RtuProgress()
+        cb = ROWS_DONE(lambda user, rows, row0, nrows: on_rows(row0, nrows)) if on_rows else ROWS_DONE()
+        prog.rows_done = cb
+        prog.cancel = ctypes.pointer(cancel) if cancel is not None else None
+        self._check(hip.rtu_multi_render_frame(self._h, ctypes.byref(frame), out.ctypes.data, ctypes.byref(prog)))
+        return out
+
+    def gather_kind(self):
+        return hip.rtu_multi_gather_kind(self._h)
+
+    def close(self):
+        if self._h:
+            hip.rtu_destroy_context_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

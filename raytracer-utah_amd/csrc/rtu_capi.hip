@@ -83,6 +83,7 @@ struct RtuContext {
     hipEvent_t cam_ev[kCamSlots] = {};
     int cam_slot = 0;
     uint32_t dbg = 0;
+    const volatile int* cancel = nullptr;    // rtu_set_cancel_flag: polled between the launch sequences of a sampled frame
     uint32_t* cover = nullptr;               // coverage masks of primary rays (KernelArgs::cover), grown on demand
     size_t    cover_cap = 0;                 // in words
     uint32_t  cover_faces = 0;
@@ -1169,6 +1170,7 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
     }
     int rounds = 0;
     for (int i = 0; i < frame->samples; i += batch) {
+        if (ctx->cancel && *ctx->cancel) return fail(ctx, RTU_ERR_CANCELLED, "cancelled after %d of %d samples", i, frame->samples);  // StopRender(), main.cpp:70-72
         int nb = frame->samples - i < batch ? frame->samples - i : batch;
         while (!gi) {
             nb = frame->samples - i < batch ? frame->samples - i : batch;  // (i may have been reset below)
@@ -1217,6 +1219,22 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
 
 extern "C" {
 
+int rtu_device_info(int device_id, RtuDeviceInfo* out) {
+    if (!out) return RTU_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device_id) != hipSuccess) return RTU_ERR_HIP;
+    out->compute_units = p.multiProcessorCount;
+    out->clock_khz = p.clockRate;
+    out->memory_clock_khz = p.memoryClockRate;
+    out->memory_bus_bits = p.memoryBusWidth;
+    out->l2_bytes = (unsigned long long)p.l2CacheSize;
+    out->hbm_bytes = (unsigned long long)p.totalGlobalMem;
+    snprintf(out->name, sizeof out->name, "%s", p.name);
+    snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    return RTU_OK;
+}
+
 int rtu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1233,6 +1251,7 @@ const char* rtu_error_string(int err) {
         case RTU_ERR_NO_SCENE: return "no scene uploaded";
         case RTU_ERR_NO_DEVICE: return "no such GPU";
         case RTU_ERR_CAPACITY: return "recursion frame capacity exceeded";
+        case RTU_ERR_CANCELLED: return "cancelled";
     }
     return "unknown error";
 }
@@ -1674,9 +1693,15 @@ int rtu_pack_image_device(RtuContext* ctx, const void* d_rgbz, size_t n_pixels, 
 
 int rtu_minmax_z_device(RtuContext* ctx, const void* d_rgbz, size_t pixels_per_frame, int n_frames, void* d_minmax, void* hip_stream) {
     if (!ctx || n_frames < 0 || pixels_per_frame > 0xFFFFFFFFull) return RTU_ERR_ARG;
-    if (pixels_per_frame == 0 || n_frames == 0) return RTU_OK;
-    if (!d_rgbz || !d_minmax) return fail(ctx, RTU_ERR_ARG, "NULL buffer");
+    if (n_frames == 0) return RTU_OK;
+    if (!d_minmax || (pixels_per_frame != 0 && !d_rgbz)) return fail(ctx, RTU_ERR_ARG, "NULL buffer");
     RTU_HIP(ctx, hipSetDevice(ctx->device));
+    if (pixels_per_frame == 0) {
+        // a shard without rows (fewer 8-row bands than ranks) still takes part in the all-reduce MIN of the keys: it must contribute
+        // the "nothing yet" keys, not whatever the buffer held (zeros would win every MIN and turn the z-image of EVERY rank black)
+        RTU_HIP(ctx, hipMemsetAsync(d_minmax, 0x7F, sizeof(long long) * 2 * (size_t)n_frames, (hipStream_t)hip_stream));
+        return RTU_OK;
+    }
     hipError_t e = (hipError_t)rtu_launch_minmax_z((const float4*)d_rgbz, (uint32_t)pixels_per_frame, (uint32_t)n_frames, (long long*)d_minmax, (hipStream_t)hip_stream);
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return RTU_OK;
@@ -1903,6 +1928,12 @@ int rtu_timeline_exits(RtuContext* ctx, int slot, int max_values, double* exit_u
     for (uint32_t j = 64; j < RTU_TL_STRIDE && n < max_values; j++)
         if (h[j]) exit_us_out[n++] = (double)(h[j] - t0) * 1e3 / (double)khz;
     return n;
+}
+
+int rtu_set_cancel_flag(RtuContext* ctx, const volatile int* flag) {
+    if (!ctx) return RTU_ERR_ARG;
+    ctx->cancel = flag;
+    return RTU_OK;
 }
 
 int rtu_debug_tail_from(RtuContext* ctx, int level) {

@@ -2,13 +2,15 @@
 # Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun):
 #   1. --kernel-trace --stats of the bench command (per-kernel durations)
 #   2. separate --pmc passes: FETCH_SIZE, WRITE_SIZE (HBM bytes), two SQ passes (instruction mix, lane utilisation, waits)
-# Outputs under gpurun_out/$TAG/; tools/profile_r02.py turns them into the summaries committed under profiles/.
+# Outputs under gpurun_out/$TAG/; tools/profile_summary.py turns them into the summaries committed under profiles/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-B="python3 bench.py --steps 48 --warmup 16 --no-cpu $BENCH_ARGS"
+# (--repeats 2: the profiler serialises and pads every launch; two regions of 64 frames are 4 launch sequences of 32 after the warm-up)
+B="python3 bench.py --steps 64 --warmup 32 --repeats 2 --no-cpu $BENCH_ARGS"
+echo "$B" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1 || exit 1

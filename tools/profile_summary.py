@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>/ (tools/profile_r02.sh) -> the evidence committed under profiles/:
+"""gpurun_out/<tag>/ (tools/profile_bench.sh) -> the evidence committed under profiles/:
   <tag>_kernel_stats.csv    rocprofv3 --stats summary of the bench command, as written by rocprofv3
   <tag>_per_kernel.txt      per kernel SLOT of the timed launch sequences (k_primary, k_trace2(L0), ...: the names bench.py and
                             rtu_kernel_slot_name use): mean duration, HBM bytes, VALU instructions per wave, lane utilisation, waits
-  <tag>_hbm_traffic.json    HBM bytes per launch per slot (FETCH_SIZE + WRITE_SIZE), read by bench.py into roofline.traffic
+  <tag>_hbm_traffic.json    HBM bytes per launch per slot (FETCH_SIZE + WRITE_SIZE)
+  <tag>_per_kernel.json     the same per slot as numbers — us, hbm_bytes_per_launch, valu_issue_frac (VALU wave-instructions per second against
+                            CUs x 4 SIMDs x clock / 4: a wave64 VALU instruction occupies a 16-lane SIMD for four cycles), lanes_active, waiting_frac —
+                            read by bench.py into roofline.{traffic, hbm_counter_frac, valu_issue_frac, lanes_active, bound}
 Only dispatches of the timed feature set (kernel template argument = the bench's frames-in-flight set, 4 / 5, or 0 / 1 with
 --frames-in-flight 1) are used; the levels of k_trace / k_trace2 / k_consume / k_combine are told apart by their order inside
 a launch sequence (a sequence starts at k_node_rects / k_primary)."""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = "gpurun_out/" + tag
 feat = sys.argv[2] if len(sys.argv) > 2 else "4"
 
@@ -33,7 +36,7 @@ def slot_names(rows):
                 seq.clear()
             continue
         k, targs = m.group(1), [t.strip() for t in m.group(2).split(",")]
-        if targs[-1] != feat or "true" in targs:
+        if targs[-1] != feat or "true" in targs or k.endswith("_counting"):
             continue
         if k == "k_primary":
             seq.clear()
@@ -103,6 +106,9 @@ def mean(v):
 
 lines = []
 traffic = {}
+perk = {}
+CUS, CLOCK_GHZ = 256, 2.4   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+VALU_PEAK = CUS * 4 * CLOCK_GHZ * 1e9 / 4  # wave64 VALU instructions per second
 order = sorted(dur, key=lambda k: -mean(dur[k]))
 total = sum(mean(dur[k]) for k in order)
 lines.append("# %s: kernel slots of the timed launch sequences (feature set %s), mean over %d sequences; rocprofv3 kernel trace + PMC passes" % (tag, feat, len(dur.get("k_primary", []))))
@@ -128,6 +134,20 @@ for k in order:
     if "TCC_HIT_sum" in c:
         l += "  L2 hit %3.0f %%" % (100 * c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]))
     lines.append(l)
+    e = {"us": round(mean(dur[k]), 2)}
+    if k in traffic:
+        e["hbm_bytes_per_launch"] = traffic[k]["hbm_bytes_per_launch"]
+    if "SQ_INSTS_VALU" in c:
+        e["waves"] = int(waves)
+        e["valu_per_wave"] = round(c["SQ_INSTS_VALU"] / waves, 1)
+        e["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] / (mean(dur[k]) * 1e-6) / VALU_PEAK, 4)
+    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
+        e["lanes_active"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]), 4)
+    if "SQ_WAIT_ANY" in c and "SQ_ACTIVE_INST_ANY" in c:
+        e["waiting_frac"] = round(c["SQ_WAIT_ANY"] / (c["SQ_WAIT_ANY"] + c["SQ_WAIT_INST_ANY"] + c["SQ_ACTIVE_INST_ANY"]), 4)
+    if "TCC_HIT_sum" in c:
+        e["l2_hit"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+    perk[k] = e
 open("profiles/%s_per_kernel.txt" % tag, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 if traffic:
@@ -136,7 +156,7 @@ if traffic:
         if line.startswith("{"):
             fif = json.loads(line)["config"]["frames_in_flight"]
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --steps 48 --warmup 16 --no-cpu",
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the command of tools/profile_bench.sh (gpurun_out/<tag>/command.txt)",
            "commit": commit, "frames_in_flight": fif,
            "note": "FETCH_SIZE / WRITE_SIZE as counted (KB x 1024). MI355X_MICROARCH.md: FETCH_SIZE halves wide coalesced 16-B-per-lane streaming reads and is "
                    "uncalibrated for other widths; this path's reads are per-lane gathers and 16-byte record reads, so the fetch figure is a lower bound "
@@ -144,3 +164,7 @@ if traffic:
            "per_kernel": traffic,
            "hbm_bytes_per_launch_sequence": int(sum(v["hbm_bytes_per_launch"] for v in traffic.values()))}
     json.dump(out, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
+    cmd = open(root + "/command.txt").read().strip() if os.path.exists(root + "/command.txt") else "python3 bench.py"
+    json.dump({"source": "rocprofv3 --kernel-trace --stats, then separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ instruction counts; SQ activity / wait / TCC hit) over the command below",
+               "command": cmd, "commit": commit, "frames_in_flight": fif, "valu_peak_wave_instructions_per_s": VALU_PEAK,
+               "sum_of_mean_kernel_us": round(total, 1), "per_kernel": perk}, open("profiles/%s_per_kernel.json" % tag, "w"), indent=1)

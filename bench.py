@@ -59,9 +59,12 @@ def hbm_peak(pkg, device):
     the machine, do not hard-code"); the guide's constant when the machine reports something implausible for an MI355X."""
     try:
         info = pkg.device_info(device)
-        gbs = 2.0 * info["memory_clock_khz"] * 1e3 * info["memory_bus_bits"] / 8 / 1e9
-        src = "hipGetDeviceProperties: memoryClockRate %d kHz x memoryBusWidth %d bit x 2 (DDR)" % (info["memory_clock_khz"], info["memory_bus_bits"])
-        if 4000.0 <= gbs <= 12000.0:
+        # HIP reports a quarter of the per-pin data rate of HBM3 / HBM3E (MI300X: 1.3 GHz x 8192 bit x 4 = 5.3 TB/s, its spec;
+        # measured here: 2.0 GHz x 8192 bit x 4 = 8.19 TB/s, the guide's "8 TB/s")
+        gbs = 4.0 * info["memory_clock_khz"] * 1e3 * info["memory_bus_bits"] / 8 / 1e9
+        src = "hipGetDeviceProperties: memoryClockRate %d kHz x memoryBusWidth %d bit x 4 (HBM3E: the reported clock is a quarter of the pin rate)" % (
+            info["memory_clock_khz"], info["memory_bus_bits"])
+        if 6000.0 <= gbs <= 10000.0:
             return gbs, src
         return HBM_PEAK_GBS, "MI355X_MICROARCH.md (8 TB/s): the device reports %s = %.0f GB/s, implausible for HBM3E x 8 stacks" % (src, gbs)
     except Exception as e:  # noqa: BLE001 — a diagnostic must not take the bench down

@@ -119,6 +119,9 @@ def main():
                     help="frames rendered by one launch sequence (rtu_render_frames_device). Default: as many as keep 2^26 pixels in "
                          "flight on a GPU, at most 128 (32 full 1080p frames, 128 shards of a quarter of the frame or less). 1: one frame per launch "
                          "sequence — the frame LATENCY configuration")
+    ap.add_argument("--rays-per-frame", type=int, default=0,
+                    help="diagnostic only: skip the (slow, untimed) counting pass that counts the reference's rays per frame and use this number instead — "
+                         "for profiler runs of sampled frames, where the counting variant would drown the timed kernels in the trace")
     ap.add_argument("--same-camera", action="store_true", help="diagnostic only: every frame of a batch from the golden camera (no turntable)")
     ap.add_argument("--samples", type=int, default=0,
                     help="diagnostic only: S >= 1 renders recipe S (S samples per pixel; soft shadows, glossy bounces, depth of field) — "
@@ -239,6 +242,10 @@ def main():
         if j and (args.same_camera or sampled):
             rays_cam.append(rays_cam[0])
             continue
+        if args.rays_per_frame:
+            keys = ["primary_rays", "secondary_rays", "shadow_rays"]
+            rays_cam.append([args.rays_per_frame // world, 0, 0])
+            continue
         ctx.render_device(mkframe(c, collect_stats=True), shard.data_ptr(), stream)
         torch.cuda.synchronize()
         st = ctx.stats()
@@ -317,22 +324,28 @@ def main():
     settle(lambda: [step(j, B) for j in range(max(1, -(-args.warmup // B)))])  # warm-up at the full batch size (>= args.warmup frames)
 
     # -- untimed: what every kernel of the launch sequence touches (the fast variant counting itself) and how long it lasts
+    # (a sampled frame is many launch sequences — one per batch of samples, ten per batch for recipe P —: its counters are sums over
+    # all launches of a slot, `launches` says how many; bytes / rays / ms below are PER LAUNCH of the slot's kernel)
     kernels = {}
     dominant = None
-    if not sampled:
+    if True:
         tframes = [mkframe(c, collect_stats=2) for c in cams]
         launch(tframes, shard)
         torch.cuda.synchronize()
         ctx.frame_status()
         kernels = ctx.touched(textured)
-        for name in kernels:
+        for name, k in kernels.items():
+            nl = max(1, k.get("launches", 1))
+            k["bytes_per_frame"], k["launches_per_frame"] = k["bytes"], nl
+            k["bytes"], k["rays"] = k["bytes"] // nl, k["rays"] // nl
             ctx.probe_kernel(name)
-            for _ in range(3):
+            for _ in range(1 if sampled else 3):
                 launch(frames, shard)
-            ms, n = ctx.probe_read()
-            kernels[name]["ms"] = ms / max(n, 1)
+            ms, n = ctx.probe_read()  # (at most 64 launches are kept per read)
+            k["ms"] = ms / max(n, 1)
         ctx.probe_kernel(None)
-        dominant = max(kernels, key=lambda k: kernels[k]["ms"])
+        # the dominant kernel: the one the launch sequences spend most time in (per launch x launches; recipe W: one launch each)
+        dominant = max(kernels, key=lambda k: kernels[k]["ms"] * kernels[k]["launches_per_frame"])
 
     batches = [min(B, args.steps - i) for i in range(0, args.steps, B)]  # EXACTLY args.steps frames
     R = max(1, args.repeats if not sampled else min(args.repeats, 3))
@@ -375,7 +388,7 @@ def main():
     ctx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
     rays_total = sum(rays_of[j] for nb in batches for j in range(nb))
 
-    seq_bytes = float(sum(k["bytes"] for k in kernels.values()))
+    seq_bytes = float(sum(k["bytes_per_frame"] for k in kernels.values()))  # of one launch sequence (recipe W) / of all sequences of one frame (sampled)
     dom_bytes = float(kernels[dominant]["bytes"]) if dominant else 0.0
     t = torch.tensor([elapsed, kernel_ms, seq_bytes, dom_ms or 0.0, dom_bytes], dtype=torch.float64, device=cdev)
     if dist:
@@ -459,8 +472,13 @@ def main():
                     "sequence": {"kernels": len(kernels), "ms": round(kernel_ms, 4), "algorithmic_bytes": int(seq_bytes),
                                  "achieved": round(seq_bytes / (kernel_ms * 1e-3) / 1e9, 2),
                                  "frac": round(seq_bytes / (kernel_ms * 1e-3) / 1e9 / peak, 5)},
-                    "kernels": {k: {"ms": round(v["ms"], 4), "bytes": v["bytes"], "rays": v["rays"],
-                                    "GBps": round(v["bytes"] / max(v["ms"], 1e-6) / 1e6, 1)} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}}
+                    "kernels": {k: dict({"ms": round(v["ms"], 4), "bytes": v["bytes"], "rays": v["rays"],
+                                         "GBps": round(v["bytes"] / max(v["ms"], 1e-6) / 1e6, 1)},
+                                        **({"launches_per_frame": v["launches_per_frame"]} if sampled else {}))
+                                for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["launches_per_frame"])}}
+            if sampled:
+                roof["per_launch"] = "a frame of %d samples is %d launches of the dominant kernel; kernel_ms, achieved and the bytes are per launch" % (
+                    args.samples, kernels[dominant]["launches_per_frame"])
             if achieved > peak:  # touched bytes served from cache faster than HBM could: say so instead of printing a "fraction" > 1
                 roof["exceeds_hbm_peak"] = True
                 print("roofline: %.0f GB/s of touched bytes exceeds the HBM peak — the dominant kernel is cache-bound, read l2_frac" % achieved, file=sys.stderr)

@@ -58,7 +58,7 @@ typedef struct RtuFrameDesc {
     int32_t max_bounce;               /* 5, RenderFunctions.cpp:134 */
     int32_t collect_stats;            /* 1: fill the ray / traversal counters RtuStats (the counting variant: the reference's own
                                          tree, no culling — slower); 2: the FAST variant as it is timed, counting per kernel what it
-                                         touches (RtuTouched; recipe W only) */
+                                         touches (RtuTouched) */
     int32_t coop_threshold;           /* tuning: a deferred-ray list shorter than this is traced by the
                                          cooperative (8 lanes per ray) kernels; 0 = default */
     int32_t samples;                  /* 0: recipe W, one ray through every pixel centre (scenes with stochastic
@@ -266,10 +266,11 @@ int  rtu_debug_tail_from(RtuContext* ctx, int level);
 int  rtu_debug_node_bounds(RtuContext* ctx, int on);
 
 /* Experiment switches for performance work (which part of a kernel costs what): bits are defined next to their use in
- * render_impl.h; bits 0..7 render WRONG images: never set them in production paths or tests of results. Two bits only switch an
+ * render_impl.h; bits 0..7 render WRONG images: never set them in production paths or tests of results. Four bits only switch an
  * optimisation off and leave every result bit alone (tests compare the images with and without): 256 = no tile occupancy
  * (k_primary tests every tile against the node rectangles and coverage masks itself), 512 = no stage-2 grid hints (both
- * stage-2 kernels of every tracing phase are launched at full size). */
+ * stage-2 kernels of every tracing phase are launched at full size), 64 = the occluder lists of shadow rays only say "empty cell or
+ * not" (every listed ray walks the BVH), 2048 = no Shade() call is settled without a frame record (every hit becomes a frame). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
@@ -314,8 +315,13 @@ typedef struct RtuTouched {
     uint64_t node_tests, mesh_box_tests, inner4, inner8, inner_ref, tri_tests, winners, xform_levels;
     uint64_t record_bytes;
     uint64_t bound_tests;     /* node-level bounds tested (24 B each: the node's world-space box) */
+    uint64_t inline_shadow_rays; /* of `rays`: shadow rays of childless Shade() calls fired by the lane that found the hit (no frame record) */
 } RtuTouched;
 int         rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots);   /* synchronises; returns the slots written */
+/* A sampled frame (recipes S / P) is many launch sequences — one per batch of samples, ten per batch for recipe P — and its counters are
+ * the sums over all of them: per_slot[i] = the number of launches of slot i's kernel that went into the table since it was zeroed
+ * (bytes per launch = rtu_touched_bytes / launches). Slot 33 is recipe P's k_gi_roots. */
+int         rtu_get_touched_launches(RtuContext* ctx, uint32_t* per_slot, int n_slots);
 unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured);
 const char* rtu_kernel_slot_name(int slot);
 

@@ -93,7 +93,7 @@ class RtuStats(ctypes.Structure):
         return {n: int(getattr(self, n)) for n in STAT_FIELDS}
 
 
-TOUCH_FIELDS = ["rays", "node_tests", "mesh_box_tests", "inner4", "inner8", "inner_ref", "tri_tests", "winners", "xform_levels", "record_bytes", "bound_tests"]
+TOUCH_FIELDS = ["rays", "node_tests", "mesh_box_tests", "inner4", "inner8", "inner_ref", "tri_tests", "winners", "xform_levels", "record_bytes", "bound_tests", "inline_shadow_rays"]
 KERNEL_SLOTS = 40
 
 
@@ -142,7 +142,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_get_touched_launches", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host", "rtu_device_info", "rtu_set_cancel_flag", "rtu_create_context_multi", "rtu_destroy_context_multi",
                "rtu_multi_size", "rtu_multi_context", "rtu_multi_last_error", "rtu_multi_upload_scene", "rtu_multi_render_frame", "rtu_multi_gather_kind"]
 _sig(hip, "rtu_device_count", _I)
@@ -165,6 +165,7 @@ _sig(hip, "rtu_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.P
 _sig(hip, "rtu_frame_status", _I, _P)
 _sig(hip, "rtu_get_touched", _I, _P, ctypes.POINTER(RtuTouched), _I)
 _sig(hip, "rtu_touched_bytes", ctypes.c_uint64, ctypes.POINTER(RtuTouched), _I)
+_sig(hip, "rtu_get_touched_launches", _I, _P, ctypes.POINTER(ctypes.c_uint32), _I)
 _sig(hip, "rtu_kernel_slot_name", ctypes.c_char_p, _I)
 _sig(hip, "rtu_probe_kernel", _I, _P, _I)
 _sig(hip, "rtu_probe_read", _I, _P, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_I))
@@ -494,11 +495,14 @@ class Context:
         n = hip.rtu_get_touched(self._h, arr, KERNEL_SLOTS)
         if n < 0:
             self._check(n)
+        nl = (ctypes.c_uint32 * KERNEL_SLOTS)()
+        hip.rtu_get_touched_launches(self._h, nl, KERNEL_SLOTS)
         out = {}
         for k in range(n):
             d = arr[k].as_dict()
             if any(d.values()):
                 d["bytes"] = int(hip.rtu_touched_bytes(ctypes.byref(arr[k]), 1 if textured else 0))
+                d["launches"] = int(nl[k])  # of this slot's kernel since the counters were zeroed (a sampled frame is many launch sequences)
                 out[hip.rtu_kernel_slot_name(k).decode()] = d
         return out
 

@@ -3,8 +3,7 @@
 #include "render_impl.h"
 
 int rtu_launch_feat21(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe) {
-    if (bvh_stack_needed <= 16) return launch_all<16, 21>(args, n_tiles, stats, stream, mode, probe);
-    if (bvh_stack_needed <= 24) return launch_all<24, 21>(args, n_tiles, stats, stream, mode, probe);
-    if (bvh_stack_needed <= 32) return launch_all<32, 21>(args, n_tiles, stats, stream, mode, probe);
+    // (one stack size: the touched-bytes mode is not timed, and neither images nor counters depend on the size of a stack that is large enough)
+    (void)bvh_stack_needed;
     return launch_all<RTU_MAX_BVH_STACK, 21>(args, n_tiles, stats, stream, mode, probe);
 }

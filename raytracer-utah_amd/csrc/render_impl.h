@@ -60,7 +60,14 @@ namespace {
 #ifndef RTU_OCC_PRIMARY
 // k_primary: six wavefronts per SIMD (<= 85 VGPRs) — the tile loop left alone takes 97 and fits five: 335 us per 16 frames against 304;
 // eight (64 VGPRs, spills): 350. k_trace / k_consume at six and the stage-2 walks at four (from five / three): slower or no change.
-#define RTU_OCC_PRIMARY __attribute__((amdgpu_waves_per_eu(6, 6)))
+// Round 3: the kernel also settles the childless Shade() calls of its hits (shadows_inline + direct_light: ground and wall pixels
+// never become frames); six wavefronts then spill 85 registers (674 us per 32 frames), four spill two (528 us), left alone it takes
+// 140 VGPRs and fits three.
+#define RTU_OCC_PRIMARY __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+#ifndef RTU_OCC_PRIMARY_S
+// k_primary_sampled (recipes S / P): five wavefronts per SIMD, no register spilled (six, as for recipe W: 13 spilled)
+#define RTU_OCC_PRIMARY_S __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 #ifndef RTU_OCC_TRACE
 // k_trace (fast variant): five wavefronts per SIMD (<= 96 VGPRs; left alone it takes 97 since the occluder-list lookups and fits four)
@@ -74,6 +81,13 @@ namespace {
 #define RTU_OCC_CONSUME
 #endif
 #define RTU_BYTES(n) do { if (CNTD) cnt.t_bytes += (n); } while (0)
+// childless Shade() calls settled by the lane that found the hit (primary_pixel), per kernel: stage 1 / the one-lane-per-ray stage 2
+#ifndef RTU_INLINE_PRIMARY
+#define RTU_INLINE_PRIMARY true
+#endif
+#ifndef RTU_INLINE_PRIMARY2
+#define RTU_INLINE_PRIMARY2 true
+#endif
 
 enum { SLOT_MAIN = 0, SLOT_A = 1, SLOT_C = 2 };
 // k_trace slot selection bits
@@ -98,7 +112,8 @@ struct Stamp {
     }
 };
 enum { RTU_TL_PRIMARY = 0, RTU_TL_PRIMARY2C = 1, RTU_TL_PRIMARY2 = 2, RTU_TL_LEVEL0 = 3 /* +4L: trace, trace2c, trace2, consume */,
-       RTU_TL_COMBINE0 = 3 + 4 * RTU_MAX_LEVELS };
+       RTU_TL_COMBINE0 = 3 + 4 * RTU_MAX_LEVELS, RTU_TL_GI_ROOTS = RTU_TL_COMBINE0 + RTU_MAX_LEVELS /* recipe P: k_gi_roots */ };
+static_assert(RTU_TL_GI_ROOTS < RTU_TL_KERNELS, "timeline slots");
 
 // Wave-aggregated append: every lane with `want` gets a unique index into the level's
 // frame arrays; one atomic per wavefront. Must be reached by all 64 lanes.
@@ -170,7 +185,7 @@ template <int TEX>
 __device__ __forceinline__ void flush_touched(const KernelArgs& a, const Counters& cnt, int kid) {
     if (!CNTD) return;
     unsigned vals[RTU_TOUCH_FIELDS] = {cnt.t_rays, cnt.t_node, cnt.t_meshbox, cnt.t_inner4, cnt.t_inner8, cnt.t_innerref, cnt.t_tri, cnt.t_win,
-                                       cnt.t_xform, cnt.t_bytes, cnt.t_bounds};
+                                       cnt.t_xform, cnt.t_bytes, cnt.t_bounds, cnt.t_inline};
 #pragma unroll
     for (int i = 0; i < RTU_TOUCH_FIELDS; i++) {
         unsigned v = vals[i];
@@ -352,8 +367,12 @@ __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
     return g;
 }
 
+template <int TEX> __device__ __forceinline__ bool shadows_inline(const KernelArgs& a, uint32_t info, f3 p, uint32_t& lit_mask, Counters& cnt);
+template <bool STATS, int TEX, class ShadowFn>
+__device__ __forceinline__ f3 direct_light(const KernelArgs& a, uint32_t info, f3 p, f3 N, f3 uvw, f3 cam_pos, f3 direct, ShadowFn sh_of);
+
 // ---- the primary ray of one pixel -------------------------------------------------------
-template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX>
+template <int STACK, bool STATS, bool DEFER, bool COOP, int TEX, bool INLINE_SHADE = false>
 __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, int x, int y, uint32_t sidx, uint32_t pix, uint32_t shard,
                                               uint32_t* stk, Counters& cnt, bool& deferred, bool leader = true,
                                               const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
@@ -419,9 +438,11 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         const size_t hb = (size_t)(a.gi_depth - 1u) * 4u * a.gi_total + pix;
         float4 hA = make_float4(0, 0, 0, 0), hB = hA, hC = hA;
         if (valid) { hA = a.gi_h[hb]; hB = a.gi_h[hb + a.gi_total]; hC = a.gi_h[hb + 2u * (size_t)a.gi_total]; }
+        if (valid && leader) RTU_BYTES(48u);  // the chain's record of the depth above
         const size_t ho = (size_t)a.gi_depth * 4u * a.gi_total + pix;
         if (valid && !(__float_as_uint(hB.w) & 1u)) {  // the chain ended above: no hit at this depth either
             if (leader) a.gi_h[ho + a.gi_total] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+            if (leader) RTU_BYTES(16u);
             valid = false;
         }
         if (valid) {
@@ -437,6 +458,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
                 a.gi_h[ho + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((hit ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(hmid + 1) << 2)));
                 a.gi_h[ho + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
                 if (TEXD) a.gi_h[ho + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+                RTU_BYTES(TEXD ? 64u : 48u);  // this depth's record
             }
         }
         return;
@@ -478,6 +500,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
                 a.gi_h[pix + a.gi_total] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float((want ? 1u : 0u) | (h.front ? 2u : 0u) | ((uint32_t)(mid + 1) << 2)));
                 a.gi_h[pix + 2u * (size_t)a.gi_total] = make_float4(ray.dir.x, ray.dir.y, ray.dir.z, __uint_as_float(smp.key));
                 if (TEXD) a.gi_h[pix + 3u * (size_t)a.gi_total] = make_float4(h.uvw.x, h.uvw.y, h.uvw.z, 0.0f);
+                RTU_BYTES(TEXD ? 64u : 48u);  // the chain's depth-0 record
                 want = false;
             }
         }
@@ -485,12 +508,30 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
     if (GID) return;
     uint32_t info = 0;
     if (want) info = make_info<TEX>(a, mid, a.frame.max_bounce, h.front, ray.dir, h.p, h.N, h.uvw, smp);
+    // A childless Shade() call is settled by the lane that found the hit (shadows_inline): no frame, the pixel is final.
+    // (rtu_debug_flags 2048 switches this off: results must not change)
+    if (!STATS && INLINE_SHADE && !(a.dbg & 2048u) && __any(want && !(info & (RTU_FI_MAIN | RTU_FI_C)))) {
+        const bool tryI = want && !(info & (RTU_FI_MAIN | RTU_FI_C));
+        uint32_t lit = ~0u;
+        bool ok = false;
+        if (tryI) ok = shadows_inline<TEX>(a, info, h.p, lit, cnt);
+        if (tryI && ok) {
+            f3 direct = mk3(0, 0, 0);
+            if (info & RTU_FI_SH) {
+                const f3 cam_pos = BATD ? ld3(a.cam[sidx].pos) : ld3(a.frame.cam_pos);  // :137: camera.pos, whatever the lens sample
+                direct = direct_light<false, TEX>(a, info, h.p, h.N, h.uvw, cam_pos, direct, [&](uint32_t j) { return ((lit >> j) & 1u) ? 1.0f : 0.0f; });
+            }
+            a.out[pix] = make_float4(direct.x, direct.y, direct.z, h.z);
+            RTU_BYTES(16u);
+            want = false;
+        }
+    }
     if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
 template <int STACK, bool STATS, int TEX>
-__global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, uint32_t n_tiles) {
+__device__ __forceinline__ void primary_stage1(const KernelArgs& a, uint32_t n_tiles) {
     const Stamp stamp(a, RTU_TL_PRIMARY);
     __shared__ uint32_t s_stack_all[STATS ? 4 * STACK * 64 : 4];
     uint32_t* stk = s_stack_all + (STATS ? (threadIdx.x >> 6) * (STACK * 64) + (threadIdx.x & 63u) : 0);
@@ -528,13 +569,22 @@ __global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, u
         }
         const uint32_t shard = btile % RTU_SHARDS;
         bool deferred;
-        primary_pixel<STACK, STATS, !STATS, false, TEX>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
+        primary_pixel<STACK, STATS, !STATS, false, TEX, RTU_INLINE_PRIMARY>(a, valid, x, y, sidx, pix, shard, stk, cnt, deferred);
         if (!STATS && !(a.dbg & 8u)) defer_push(a, 0, shard, deferred, pix);
         if (deferred) RTU_BYTES(4u);
     }
     flush_counters<STATS>(a, cnt);
     flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY);
 }
+// (three kernels around one body: the occupancy hint is recipe W's fast variant's — mostly background tiles and stores; the sampled
+// and path-traced variants carry the lens / hemisphere sampling in binary64 and spill 13 registers under it, the counting variant
+// keeps a traversal stack per lane)
+template <int STACK, bool STATS, int TEX>
+__global__ void __launch_bounds__(256) RTU_OCC_PRIMARY k_primary(KernelArgs a, uint32_t n_tiles) { primary_stage1<STACK, STATS, TEX>(a, n_tiles); }
+template <int STACK, int TEX>
+__global__ void __launch_bounds__(256) RTU_OCC_PRIMARY_S k_primary_sampled(KernelArgs a, uint32_t n_tiles) { primary_stage1<STACK, false, TEX>(a, n_tiles); }
+template <int STACK, int TEX>
+__global__ void __launch_bounds__(256) k_primary_counting(KernelArgs a, uint32_t n_tiles) { primary_stage1<STACK, true, TEX>(a, n_tiles); }
 
 // Stage the top of every mesh's 8-wide tree (BFS order) into the workgroup's LDS node area.
 __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nodes) {
@@ -571,7 +621,7 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
         uint32_t sidx;
         pixel_of<TEX>(a, pix, x, y, sidx);
         bool deferred;
-        primary_pixel<STACK, false, false, false, TEX>(a, valid, x, y, sidx, pix, shard, s_stack + lane, cnt, deferred);
+        primary_pixel<STACK, false, false, false, TEX, RTU_INLINE_PRIMARY2>(a, valid, x, y, sidx, pix, shard, s_stack + lane, cnt, deferred);
     }
     flush_touched<TEX>(a, cnt, RTU_TL_PRIMARY2);
 }
@@ -847,6 +897,108 @@ __device__ __forceinline__ f3 finalize(const DevScene& s, const RTU_CONST RtuMat
     return result;
 }
 
+// The light loop of MtlBlinn::Shade (mtlFunctions.cpp:125-155) of one Shade() call with RTU_FI_SH, in light-list order, added to
+// `direct` (what the call has accumulated so far: zero, or the AmbientLight term of recipe P). sh_of(j): Shadow() of non-ambient
+// light j (asked only where a shadow ray was fired). Shared by k_consume / k_tail (results from the level's shadow array) and by
+// the inline shading of childless Shade() calls (results in registers).
+template <bool STATS, int TEX, class ShadowFn>
+__device__ __forceinline__ f3 direct_light(const KernelArgs& a, uint32_t info, f3 p, f3 N, f3 uvw, f3 cam_pos, f3 direct, ShadowFn sh_of) {
+    const DevScene& s = a.scene;
+    const RTU_CONST RtuMaterial& m = as_const(s.materials)[info & RTU_FI_MTL_MASK];
+    {
+        const int mtl = (int)(info & RTU_FI_MTL_MASK);
+        const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
+        const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
+        uint32_t j = 0;  // index among the non-ambient lights
+        const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
+        // A MATERIAL WITHOUT A SPECULAR COLOUR (walls, floors: `specular value="0"`) does not need its highlight: the light's term
+        // is (Illuminate * N.L) * (diffuse + specular * pow(N.H, glossiness)) (:152), and with specular = +-0 in every channel the
+        // second factor is `diffuse` bit for bit PROVIDED pow() is finite — +-0 * finite = +-0, and x + +-0 = x unless x is -0
+        // (excluded below) —: no half vector (a square root, three divisions), no N.H, no powf (~150 instructions on this
+        // device). pow(N.H, g) is finite when N.H is a number in [0, 1 + 1e-6] and 0 <= g <= 1e6. N.H = N . normalize(V + L) is a
+        // NaN exactly when N is (then N.L is too and the term is NaN whatever the second factor) or when the half vector is:
+        // V + L zero or NaN (the light straight behind the surface point as seen from the camera; the camera or a light AT the
+        // point) — the loop below takes the literal path then (`hh > 0` fails). The counting variant always takes the literal
+        // path: every test that compares the two variants checks this identity, NaN pixels included.
+        const bool noHighlight = !STATS && specular.x == 0.0f && specular.y == 0.0f && specular.z == 0.0f &&
+                                 m.glossiness >= 0.0f && m.glossiness <= 1e6f && __float_as_uint(diffuse.x) != 0x80000000u &&
+                                 __float_as_uint(diffuse.y) != 0x80000000u && __float_as_uint(diffuse.z) != 0x80000000u;
+        for (uint32_t i = 0; i < s.n_lights; i++) {
+            const RTU_CONST RtuLight& l = as_const(s.lights)[i];
+            const f3 intensity = ld3(l.intensity);
+            if (l.type == RTU_LIGHT_AMBIENT) {
+                direct = direct + diffuse * intensity;  // :132
+                continue;
+            }
+            const f3 lvec = ld3(l.vec);
+            const bool isDirect = l.type == RTU_LIGHT_DIRECT;
+            const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
+            const f3 lightDirection = norm3(-ldir);                       // :138
+            const f3 hsum = viewDirection + lightDirection;
+            float NDotL = dot3(N, lightDirection);
+            if (NDotL < 0.0f) NDotL = 0.0f;
+            f3 second = diffuse;  // diffuse + specular * pow(N.H, glossiness) of a material without a specular colour
+            if (!(noHighlight && dot3(hsum, hsum) > 0.0f)) {
+                const f3 halfVector = norm3(hsum);  // :139
+                float NDotH = dot3(N, halfVector);
+                if (NDotH < 0.0f) NDotH = 0.0f;
+                second = diffuse + specular * powf(NDotH, m.glossiness);
+            }
+            const bool behind = !STATS && j < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + j)) & 1u);  // no shadow ray was fired (make_info)
+            const float sh = behind ? 1.0f : sh_of(j);
+            j++;
+            f3 illum;
+            if (isDirect) {
+                illum = intensity * sh;  // lights.h:48
+            } else {
+                const f3 d = lvec - p;
+                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
+            }
+            direct = direct + (illum * NDotL) * second;  // :152
+        }
+    }
+    return direct;
+}
+
+// CHILDLESS Shade() CALLS WITHOUT A FRAME. A Shade() call that fires no secondary ray (no refraction / reflection property, or
+// bounce 0) is its light loop and nothing else (mtlFunctions.cpp:125-155, then `return result`): Shadow() of every non-ambient
+// light, then direct_light. With the occluder lists (rtu_intersect.h mesh_shadow_cells) a hard shadow ray needs no BVH walk, so
+// the lane that found the hit can settle the whole call itself: no frame record written and read back three times, no k_trace /
+// k_consume round trip. shadows_inline fires the shadow rays of one call; it returns false for a lane whose ray cannot be
+// settled without a walk (a mesh without a list for that light, a list entry within rounding of a bounding box, a soft shadow):
+// that lane's call becomes a frame as before. Same rays, same arithmetic, same order within the call.
+template <int TEX>
+__device__ __forceinline__ bool shadows_inline(const KernelArgs& a, uint32_t info, f3 p, uint32_t& lit_mask, Counters& cnt) {
+    const DevScene& s = a.scene;
+    lit_mask = ~0u;  // bit j: Shadow() of non-ambient light j returned 1
+    bool ok = true;
+    if (!(info & RTU_FI_SH)) return true;
+    for (uint32_t slot = 0; slot < a.nsl; slot++) {
+        if (slot < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + slot)) & 1u)) continue;  // behind the surface: its term is +-0 (make_info)
+        const RTU_CONST RtuLight& l = as_const(s.lights)[a.shadow_light[slot]];
+        const f3 lvec = ld3(l.vec);
+        Ray r;
+        r.p = p;
+        float tmax = RTU_BIGFLOAT;
+        if (l.type == RTU_LIGHT_DIRECT) {
+            r.dir = -lvec;
+        } else {
+            if (SMPD && l.size > 0) ok = false;  // a soft shadow: the ray aims at a sample of the light's disk (frame_ray)
+            r.dir = norm3(lvec - p);
+            tmax = len3(lvec - p);
+        }
+        Hit h;
+        fresh_hit(h, tmax);
+        bool deferred = false;
+        if (CNTD) cnt.t_inline++;
+        const bool hit = trace<1, false, true, true, false, TEXD, CNTD, true, true>(s, r, true, h, nullptr, cnt, deferred, 64, nullptr, 0ull, false,
+                                                                                      slot < RTU_LMASK_LIGHTS ? (int)slot : -1);
+        if (deferred) ok = false;
+        if (hit && h.z > 0.0f) lit_mask &= ~(1u << slot);
+    }
+    return ok;
+}
+
 // One Shade() frame after its rays are traced (the body of k_consume; also used by k_tail): direct
 // lighting, children, lists. Wave-uniform: all 64 lanes call it, `active` says whether the lane has
 // a frame. shard: the frame's own shard; cshard: where its children go. st_out: the children.
@@ -899,56 +1051,9 @@ __device__ __forceinline__ void consume_frame(const KernelArgs& a, int L, uint32
     }
     if (active && (info & RTU_FI_SH)) {
         RTU_BYTES(4u * a.nsl);
-        const int mtl = (int)(info & RTU_FI_MTL_MASK);
-        const f3 diffuse = mtl_color<TEXD>(s, mtl, RTU_MAP_DIFFUSE, ld3(m.diffuse), uvw);
-        const f3 specular = mtl_color<TEXD>(s, mtl, RTU_MAP_SPECULAR, ld3(m.specular), uvw);
-        uint32_t j = 0;  // index among the non-ambient lights
-        const f3 viewDirection = norm3(cam_pos - p);  // :137 (the same value for every light)
-        // A MATERIAL WITHOUT A SPECULAR COLOUR (walls, floors: `specular value="0"`) does not need its highlight: the light's term
-        // is (Illuminate * N.L) * (diffuse + specular * pow(N.H, glossiness)) (:152), and with specular = +-0 in every channel the
-        // second factor is `diffuse` bit for bit PROVIDED pow() is finite — +-0 * finite = +-0, and x + +-0 = x unless x is -0
-        // (excluded below) —: no half vector (a square root, three divisions), no N.H, no powf (~150 instructions on this
-        // device). pow(N.H, g) is finite when N.H is a number in [0, 1 + 1e-6] and 0 <= g <= 1e6. N.H = N . normalize(V + L) is a
-        // NaN exactly when N is (then N.L is too and the term is NaN whatever the second factor) or when the half vector is:
-        // V + L zero or NaN (the light straight behind the surface point as seen from the camera; the camera or a light AT the
-        // point) — the loop below takes the literal path then (`hh > 0` fails). The counting variant always takes the literal
-        // path: every test that compares the two variants checks this identity, NaN pixels included.
-        const bool noHighlight = !STATS && specular.x == 0.0f && specular.y == 0.0f && specular.z == 0.0f &&
-                                 m.glossiness >= 0.0f && m.glossiness <= 1e6f && __float_as_uint(diffuse.x) != 0x80000000u &&
-                                 __float_as_uint(diffuse.y) != 0x80000000u && __float_as_uint(diffuse.z) != 0x80000000u;
-        for (uint32_t i = 0; i < s.n_lights; i++) {
-            const RTU_CONST RtuLight& l = as_const(s.lights)[i];
-            const f3 intensity = ld3(l.intensity);
-            if (l.type == RTU_LIGHT_AMBIENT) {
-                direct = direct + diffuse * intensity;  // :132
-                continue;
-            }
-            const f3 lvec = ld3(l.vec);
-            const bool isDirect = l.type == RTU_LIGHT_DIRECT;
-            const f3 ldir = isDirect ? lvec : norm3(p - lvec);           // Direction(), lights.h:49,83
-            const f3 lightDirection = norm3(-ldir);                       // :138
-            const f3 hsum = viewDirection + lightDirection;
-            float NDotL = dot3(N, lightDirection);
-            if (NDotL < 0.0f) NDotL = 0.0f;
-            f3 second = diffuse;  // diffuse + specular * pow(N.H, glossiness) of a material without a specular colour
-            if (!(noHighlight && dot3(hsum, hsum) > 0.0f)) {
-                const f3 halfVector = norm3(hsum);  // :139
-                float NDotH = dot3(N, halfVector);
-                if (NDotH < 0.0f) NDotH = 0.0f;
-                second = diffuse + specular * powf(NDotH, m.glossiness);
-            }
-            const bool behind = !STATS && j < RTU_FI_NOL_LIGHTS && ((info >> (RTU_FI_NOL_SH + j)) & 1u);  // no shadow ray was fired (make_info)
-            const float sh = behind ? 1.0f : (pre && j < 2u) ? (j == 0u ? pre->sh0 : pre->sh1) : lv.fsh[(size_t)f * a.nsl + j];
-            j++;
-            f3 illum;
-            if (isDirect) {
-                illum = intensity * sh;  // lights.h:48
-            } else {
-                const f3 d = lvec - p;
-                illum = (intensity * (0.0f + sh)) * (1 / dot3(d, d));  // lightFunctions.cpp:78-83
-            }
-            direct = direct + (illum * NDotL) * second;  // :152
-        }
+        direct = direct_light<STATS, TEX>(a, info, p, N, uvw, cam_pos, direct, [&](uint32_t j) {
+            return (pre && j < 2u) ? (j == 0u ? pre->sh0 : pre->sh1) : lv.fsh[(size_t)f * a.nsl + j];
+        });
     }
 
     // ---- secondary-ray hits become frames of the next level ----
@@ -1282,12 +1387,14 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
 // intensity c = Shade(h_k+1, its own AmbientLight) + Shade(h_k+1, lights) (:568-570), the environment along
 // the gather ray if it missed (:575), or 0.1 at the last bounce (:584). This kernel computes c for every
 // chain that has a hit of depth a.gi_depth and appends the two Shade() trees of that hit as level-0 frames.
+// inline_ok: the fast variant (the counting variant materialises every Shade() call as a frame: its counters are the reference's).
 template <int TEX>
-__global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
+__global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a, int inline_ok) {
     const DevScene& s = a.scene;
     const uint32_t lane = threadIdx.x;
     const uint32_t k = a.gi_depth;
     const uint32_t chunks = (a.gi_total + 63u) / 64u;
+    Counters cnt = {};
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t chain = c * 64u + lane;
         const uint32_t shard = c % RTU_SHARDS;
@@ -1297,11 +1404,13 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
         if (chain < a.gi_total) {
             hB = a.gi_h[hb + a.gi_total];
             want = (__float_as_uint(hB.w) & 1u) != 0;
+            RTU_BYTES(16u);
         }
         if (want) {
             hA = a.gi_h[hb];
             hC = a.gi_h[hb + 2u * (size_t)a.gi_total];
             if (TEXD) hD = a.gi_h[hb + 3u * (size_t)a.gi_total];
+            RTU_BYTES(TEXD ? 48u : 32u);
         }
         const uint32_t pk = __float_as_uint(hB.w);
         const int mid = (int)(pk >> 2) - 1;
@@ -1309,6 +1418,7 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
         if (want && k < (uint32_t)RTU_GI_BOUNCES) {
             const size_t hn = (size_t)(k + 1u) * 4u * a.gi_total + chain;
             const uint32_t npk = __float_as_uint(a.gi_h[hn + a.gi_total].w);
+            RTU_BYTES(16u + ((npk & 1u) ? ((int)(npk >> 2) - 1 < 0 ? 0u : 32u) : 16u));  // the depth below: its hit flag, then its two results or its ray
             if (npk & 1u) {
                 if ((int)(npk >> 2) - 1 < 0) {
                     amb = (mk3(0, 0, 0) + mk3(1, 1, 1)) + mk3(1, 1, 1);  // a node without material shades white, twice
@@ -1324,6 +1434,7 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
         if (want && mid < 0) {  // no material at this hit: both trees are white, nothing to trace
             a.gi_res[chain] = make_float4(1, 1, 1, 0);
             a.gi_res[(size_t)a.gi_total + chain] = make_float4(1, 1, 1, 0);
+            RTU_BYTES(32u);
             want = false;
         }
         const f3 p = mk3(hA.x, hA.y, hA.z), N = mk3(hB.x, hB.y, hB.z), dir = mk3(hC.x, hC.y, hC.z), uvw = mk3(hD.x, hD.y, hD.z);
@@ -1337,11 +1448,36 @@ __global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a) {
             ia = make_info<TEX>(a, mid, a.frame.max_bounce, front, dir, p, N, uvw, sa, true);
             id = make_info<TEX>(a, mid, a.frame.max_bounce, front, dir, p, N, uvw, sd, false);
         }
-        Counters cnt = {};
-        const uint32_t fa_idx = append_root<TEX>(a, want, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw, cnt);
-        if (want && fa_idx != ~0u) a.lv[0].famb[fa_idx] = make_float4(amb.x, amb.y, amb.z, 0.0f);
-        append_root<TEX>(a, want, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw, cnt);
+        // A childless Shade() call (no refraction / reflection property: every material of config 5's scene) needs no frame:
+        //  * the tree lit by MonteCarlo()'s AmbientLight is `diffuse * intensity` on a front face (mtlFunctions.cpp:125-132) — what
+        //    consume_frame computes for an RTU_FI_AMB frame without children;
+        //  * the tree lit by the scene's lights is its light loop, settled here when every shadow ray can be (shadows_inline).
+        bool wantA = want, wantD = want;
+        if (inline_ok && want && !(ia & (RTU_FI_MAIN | RTU_FI_C))) {
+            f3 direct = mk3(0, 0, 0);
+            if (ia & RTU_FI_FRONT) direct = direct + mtl_color<TEXD>(s, mid, RTU_MAP_DIFFUSE, ld3(as_const(s.materials)[mid].diffuse), uvw) * amb;
+            a.gi_res[chain] = make_float4(direct.x, direct.y, direct.z, 0.0f);
+            RTU_BYTES(16u);
+            wantA = false;
+        }
+        if (inline_ok && __any(want && !(id & (RTU_FI_MAIN | RTU_FI_C)))) {
+            const bool tryD = want && !(id & (RTU_FI_MAIN | RTU_FI_C));
+            uint32_t lit = ~0u;
+            bool ok = false;
+            if (tryD) ok = shadows_inline<TEX>(a, id, p, lit, cnt);
+            if (tryD && ok) {
+                f3 direct = mk3(0, 0, 0);
+                if (id & RTU_FI_SH) direct = direct_light<false, TEX>(a, id, p, N, uvw, ld3(a.frame.cam_pos), direct, [&](uint32_t j) { return ((lit >> j) & 1u) ? 1.0f : 0.0f; });
+                a.gi_res[(size_t)a.gi_total + chain] = make_float4(direct.x, direct.y, direct.z, 0.0f);
+                RTU_BYTES(16u);
+                wantD = false;
+            }
+        }
+        const uint32_t fa_idx = append_root<TEX>(a, wantA, shard, ia, p, N, sa.key, dir, __uint_as_float(chain), uvw, cnt);
+        if (wantA && fa_idx != ~0u) { a.lv[0].famb[fa_idx] = make_float4(amb.x, amb.y, amb.z, 0.0f); RTU_BYTES(16u); }
+        append_root<TEX>(a, wantD, shard, id, p, N, sd.key, dir, __uint_as_float(chain), uvw, cnt);
     }
+    flush_touched<TEX>(a, cnt, RTU_TL_GI_ROOTS);
 }
 
 // NODE-LEVEL BOUNDS of primary rays (recipe W): per camera of the launch and per node, the rectangle of pixels whose
@@ -1615,9 +1751,10 @@ __global__ void __launch_bounds__(64) k_tile_occ(KernelArgs a, uint32_t entries)
 #define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
     do {                                                                                     \
         const bool probed_ = probe && probe->slot == (kslot_);                               \
+        if (a.host_launches) a.host_launches[(kslot_)]++;                                    \
         if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev0, stream);                   \
         hipLaunchKernelGGL(kernel, grid, blk, 0, stream, __VA_ARGS__);                       \
-        if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev1, stream);                   \
+        if (probed_) { (void)hipEventRecord((hipEvent_t)probe->ev1, stream); if (probe->recorded) *probe->recorded = 1; } \
     } while (0)
 
 template <int STACK, int TEX>
@@ -1651,9 +1788,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     const dim3 gridP(blocksP), gridPF(blocksP < 32768u ? blocksP : 32768u);
     if (CNTD) stats = false;  // the touched-bytes instantiations are the fast variant's (the reference-counting kernels are not built for them)
     if (mode == RTU_LAUNCH_SHADE) {
-        hipLaunchKernelGGL((k_gi_roots<TEX>), gridN, block, 0, stream, a);
+        RTU_LAUNCH(RTU_TL_GI_ROOTS, (k_gi_roots<TEX>), gridN, block, a, (stats || (a.dbg & 2048u)) ? 0 : 1);  // (rtu_debug_flags 2048: no inline shading — results must not change)
     } else if (stats) {
-        if constexpr (!CNTD) hipLaunchKernelGGL((k_primary<STACK, true, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
+        if constexpr (!CNTD) hipLaunchKernelGGL((k_primary_counting<STACK, TEX>), gridP, dim3(256), 0, stream, a, n_tiles);
     } else {
         if (!SMPD && a.node_rects) {
             const uint32_t entries = BATD ? a.batch : 1u;
@@ -1664,7 +1801,8 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             hipLaunchKernelGGL(k_prelude, dim3(gx, rows), dim3(256), a.cover ? a.cover_words * sizeof(uint32_t) : 0, stream, a, entries);
         }
         if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
-        RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
+        if constexpr (SMPD || GID) RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary_sampled<STACK, TEX>), gridPF, dim3(256), a, n_tiles);
+        else RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
         if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
             RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);

@@ -247,6 +247,10 @@ int rtu_launch_feat10(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_sta
 int rtu_launch_feat11(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 int rtu_launch_feat16(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 int rtu_launch_feat17(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat18(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat19(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat26(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
+int rtu_launch_feat27(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 int rtu_launch_feat20(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 int rtu_launch_feat21(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, bool stats, hipStream_t stream, int mode, const LaunchProbe* probe);
 
@@ -255,15 +259,18 @@ int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stac
     // uvw, sample nothing and draw nothing.
     const bool ref = stats == 1;
     if (mode != RTU_LAUNCH_ALL) {
-        if (stats == 2) return (int)hipErrorInvalidValue;
+        if (stats == 2) return args.scene.textured ? rtu_launch_feat27(args, n_tiles, bvh_stack_needed, false, stream, mode, probe)
+                                                   : rtu_launch_feat26(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
         if (args.scene.textured) return rtu_launch_feat11(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
         return rtu_launch_feat10(args, n_tiles, bvh_stack_needed, ref, stream, mode, probe);
     }
     const int feat = (args.scene.textured ? 1 : 0) | (args.sampling ? 2 : (args.frame_batch ? 4 : 0));
-    if (stats == 2) {  // touched-bytes mode: recipe W, one frame or frames in flight
+    if (stats == 2) {  // touched-bytes mode: one frame, frames in flight, or a batch of samples
         switch (feat) {
             case 0: return rtu_launch_feat16(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
             case 1: return rtu_launch_feat17(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            case 2: return rtu_launch_feat18(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
+            case 3: return rtu_launch_feat19(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
             case 4: return rtu_launch_feat20(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
             case 5: return rtu_launch_feat21(args, n_tiles, bvh_stack_needed, false, stream, mode, probe);
             default: return (int)hipErrorInvalidValue;

@@ -66,6 +66,7 @@ struct RtuContext {
     float4* fb = nullptr;
     size_t  fb_bytes = 0;
     unsigned long long* counters = nullptr;  // 11 x u64 (RtuStats), or the touched-bytes table [RTU_TL_KERNELS][RTU_TOUCH_STRIDE]
+    uint32_t slot_launches[RTU_TL_KERNELS] = {};  // touched-bytes mode: launches per slot that went into the table (rtu_get_touched_launches)
     // probe: HIP events around the launches of one timeline slot (rtu_probe_kernel)
     static const int kProbePairs = 64;
     int probe_slot = -1, probe_used = 0;
@@ -823,7 +824,6 @@ int check_frame(RtuContext* ctx, const RtuFrameDesc* f) {
     if (f->gather_bounces != 0 && (f->gather_bounces != RTU_GI_BOUNCES || f->samples < 1))
         return fail(ctx, RTU_ERR_ARG, "gather_bounces is 0 or %d (recipe P, with samples >= 1)", RTU_GI_BOUNCES);
     if (f->collect_stats < 0 || f->collect_stats > 2) return fail(ctx, RTU_ERR_ARG, "collect_stats is 0, 1 or 2");
-    if (f->collect_stats == 2 && f->samples != 0) return fail(ctx, RTU_ERR_ARG, "the touched-bytes mode (collect_stats == 2) covers recipe W (samples == 0)");
     if (f->samples == 0 && ctx->has_scene && (ctx->scene_stochastic || f->dof != 0))
         return fail(ctx, RTU_ERR_STOCHASTIC, "the scene has %s: render it with frame.samples >= 1 (recipe S)",
                     ctx->scene_stochastic ? ctx->stochastic_what.c_str() : "depth of field");
@@ -940,7 +940,10 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         }
     }
     const int stats = frame->collect_stats;  // 0 fast, 1 reference counting, 2 touched bytes of the fast variant
-    if (stats && zero_counters) RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kCounterBytes, stream));
+    if (stats && zero_counters) {
+        RTU_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kCounterBytes, stream));
+        memset(ctx->slot_launches, 0, sizeof ctx->slot_launches);
+    }
     // the append counters start at zero; `overflow` is STICKY — launches only ever set it, check_overflow reads and clears
     // it — so that a frame that ran out of capacity is reported even when later launch sequences were queued behind it
     RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt, 0, offsetof(FrameCounters, overflow), stream));
@@ -958,6 +961,7 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.dbg = ctx->dbg;
     a.scene.dbg = ctx->dbg;
     a.counters = stats ? ctx->counters : nullptr;
+    a.host_launches = stats == 2 ? ctx->slot_launches : nullptr;
     a.node_rects = (stats != 1 && frame->samples == 0 && ctx->dscene.node_bounds) ? ctx->node_rects : nullptr;
     if (a.node_rects && (ctx->dscene.n_cover + ctx->dscene.n_pcover) && !gi && ((size_t)((frame->width + 7) / 8) * (size_t)((frame->height + 7) / 8) + 31u) / 32u <= 12288u) {  // (the mask has to fit k_mesh_cover's LDS copy)
         a.tiles_xf = (uint32_t)((frame->width + 7) / 8);
@@ -1052,22 +1056,24 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
     memcpy(a.nol_light, ctx->nol_light, sizeof a.nol_light);
+    int probe_recorded = 0;
+    LaunchProbe probe{-1, nullptr, nullptr, &probe_recorded};
+    const bool probing = ctx->probe_slot >= 0 && ctx->probe_used < RtuContext::kProbePairs;
+    if (probing) {
+        probe.slot = ctx->probe_slot;
+        probe.ev0 = ctx->probe_ev[2 * ctx->probe_used];
+        probe.ev1 = ctx->probe_ev[2 * ctx->probe_used + 1];
+    }
     if (gi_mode == RTU_LAUNCH_SHADE && gi_depth == 0) {
-        hipError_t e0 = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode);
+        hipError_t e0 = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode, probing ? &probe : nullptr);
+        if (probing && probe_recorded) ctx->probe_used++;
         if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
         e0 = (hipError_t)rtu_launch_gi_final(a, stream);  // harmless if this step has to be repeated: it only reads the results
         if (e0 != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e0));
         return RTU_OK;
     }
-    LaunchProbe probe{-1, nullptr, nullptr};
-    const bool probing = ctx->probe_slot >= 0 && gi_mode == RTU_LAUNCH_ALL && ctx->probe_used < RtuContext::kProbePairs;
-    if (probing) {
-        probe.slot = ctx->probe_slot;
-        probe.ev0 = ctx->probe_ev[2 * ctx->probe_used];
-        probe.ev1 = ctx->probe_ev[2 * ctx->probe_used + 1];
-        ctx->probe_used++;
-    }
     hipError_t e = (hipError_t)rtu_launch_frame(a, n_tiles, ctx->bvh_stack_needed, stats, stream, gi_mode, probing ? &probe : nullptr);
+    if (probing && probe_recorded) ctx->probe_used++;
     if (e != hipSuccess) return fail(ctx, RTU_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return RTU_OK;
 }
@@ -1744,6 +1750,13 @@ int rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots) {
     return n;
 }
 
+int rtu_get_touched_launches(RtuContext* ctx, uint32_t* per_slot, int n_slots) {
+    if (!ctx || !per_slot || n_slots < 0) return RTU_ERR_ARG;
+    const int n = n_slots < RTU_TL_KERNELS ? n_slots : RTU_TL_KERNELS;
+    for (int i = 0; i < n; i++) per_slot[i] = ctx->slot_launches[i];
+    return n;
+}
+
 unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured) {
     if (!t) return 0;
     return 24ull * t->bound_tests + 48ull * t->node_tests + 24ull * t->mesh_box_tests + 84ull * t->xform_levels + 112ull * t->inner4 + 256ull * t->inner8 +
@@ -1758,7 +1771,9 @@ const char* rtu_kernel_slot_name(int slot) {
     if (slot == 1) return "k_primary2c";
     if (slot == 2) return "k_primary2";
     if (slot < 3 + 4 * RTU_MAX_LEVELS) snprintf(buf[slot], sizeof buf[slot], "%s(L%d)", level_kernels[(slot - 3) % 4], (slot - 3) / 4);
-    else snprintf(buf[slot], sizeof buf[slot], "k_combine(L%d)", slot - (3 + 4 * RTU_MAX_LEVELS));
+    else if (slot < 3 + 5 * RTU_MAX_LEVELS) snprintf(buf[slot], sizeof buf[slot], "k_combine(L%d)", slot - (3 + 4 * RTU_MAX_LEVELS));
+    else if (slot == 3 + 5 * RTU_MAX_LEVELS) return "k_gi_roots";
+    else return "";
     return buf[slot];
 }
 

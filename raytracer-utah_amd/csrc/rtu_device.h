@@ -244,7 +244,7 @@ struct LevelBuffers {
 #define RTU_TAIL_LEARN   256u   // the host hands levels to k_tail when the cut level held at most this many frames last time
 #define RTU_TAIL_DECLINE 4096u  // ... and k_tail refuses a cut level with more than this many (the hint was for another view)
 #define RTU_TL_KERNELS 40   // timeline slots: 3 primary + 4 per level + 6 combine (render_impl.h)
-#define RTU_TOUCH_FIELDS 11  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
+#define RTU_TOUCH_FIELDS 12  // Counters::t_* (rtu_intersect.h), RtuTouched (rtu_render.h)
 #define RTU_TOUCH_STRIDE 16  // u64 per timeline slot in the counter table of the touched-bytes mode
 #define RTU_TL_ENDS 8192u   // exit-stamp slots per kernel (wavefront index modulo; a later wavefront overwrites an earlier one)
 #define RTU_TL_STRIDE (64u + RTU_TL_ENDS)
@@ -308,6 +308,7 @@ struct KernelArgs {
     // expected to be idle gets a smaller grid: the one-lane-per-ray kernel one that would still get through twice the last
     // list, the cooperative kernel a token one when the list was beyond twice the threshold. Any grid renders the same image.
     uint32_t     list_n[8];
+    uint32_t*    host_launches;     // HOST ONLY (launch_all), touched-bytes mode: launches per timeline slot since the counters were zeroed, or nullptr
     // recipe S (frame.samples >= 1): one launch sequence per sample
     // `batch` consecutive samples at once, as [sample][pixel of the shard] (longer ray lists fill the chip better)
     uint32_t     sampling;          // 0: recipe W
@@ -340,6 +341,7 @@ struct LaunchProbe {
     int   slot;
     void* ev0;
     void* ev1;
+    int*  recorded;   // set to 1 when the sequence did launch that slot's kernel (a chain launch of recipe P has no k_gi_roots, ...)
 };
 int rtu_launch_frame(const KernelArgs& args, uint32_t n_tiles, uint32_t bvh_stack_needed, int stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL,
                      const LaunchProbe* probe = nullptr);

@@ -40,6 +40,7 @@ struct Counters {
     // touched-bytes mode of the FAST variant (collect_stats == 2, RtuTouched in rtu_render.h): what the timed
     // kernels themselves read and write — their own trees, their own culling, their own two stages
     unsigned t_rays, t_node, t_meshbox, t_inner4, t_inner8, t_innerref, t_tri, t_win, t_xform, t_bytes, t_bounds;
+    unsigned t_inline;  // of t_rays: shadow rays of childless Shade() calls settled by the lane that found the hit (render_impl.h shadows_inline)
 };
 
 #define RTU_CNT(field) do { if (STATS) cnt.field++; } while (0)
@@ -1047,7 +1048,9 @@ __device__ __forceinline__ int mesh_shadow_cells(const uint32_t* cell_tri, uint3
 // and exact test. (The margin is 100 x the slab rounding; the bound of a sphere is widened further at upload by what the
 // cancellation in its discriminant can move a grazing root, rtu_capi.hip world_bounds.) `skip` marks nodes the caller
 // has already excluded in the same sense: for primary rays, pixels outside the node's screen rectangle (k_node_rects).
-template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false, bool ULS = DEFER>
+// INL (with DEFER): the occluder lists are walked HERE, in stage 1 (the inline shading of childless Shade() calls, render_impl.h
+// shadows_inline): `deferred` then means "this ray cannot be settled without a BVH walk".
+template <int STACK, bool STATS, bool CULL, bool DEFER, bool COOP = false, bool TEX = false, bool FC = false, bool ULS = DEFER, bool INL = false>
 __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool shadow, Hit& h, uint32_t* stk, Counters& cnt, bool& deferred,
                                       const uint32_t stride = 64, const float4* lds_nodes = nullptr, const unsigned long long skip = 0,
                                       const bool rays_bounded = false, const int lslot = -1) {
@@ -1156,7 +1159,7 @@ __device__ __forceinline__ bool trace(const DevScene& s, const Ray& wr, bool sha
             // stage 1 only looks the cell up: a ray with entries to test joins the defer list, where stage 2 finds it among rays
             // that all have a list to walk (inline, a fifth of a wavefront's rays walked theirs while the others waited, and the
             // kernel's registers cost it two of its five wavefronts per SIMD: measured, no faster than this and 10 % slower alone)
-            const int code = DEFER ? 2 : mesh_shadow_cells<FC, ULS, COOP ? 8u : 1u>(ltri, le0, le1, ldepth, mesh, lr, h.z, cnt, fc_lane);
+            const int code = (DEFER && !INL) ? 2 : mesh_shadow_cells<FC, ULS, COOP ? 8u : 1u>(ltri, le0, le1, ldepth, mesh, lr, h.z, cnt, fc_lane);
             hit = code == 1;
             if (code == 2) {  // within rounding of a bounding box: the reference's own walk decides
                 if (DEFER) deferred = true;

@@ -715,8 +715,10 @@ def test_touched_bytes_mode_is_the_fast_variant_counting_itself(pkg, ctx, golden
         for i in range(fif):
             assert np.array_equal(out[i].view(np.uint32), fast[i].view(np.uint32)), "touched-bytes mode changed the image"
         _, deferred = ctx.frame_counts()
-        assert t["k_primary"]["rays"] == fif * W * H
-        st2 = t.get("k_primary2", {"rays": 0})["rays"] + t.get("k_primary2c", {"rays": 0})["rays"]
+        # (a primary kernel also fires the shadow rays of the childless Shade() calls it settles itself: counted apart)
+        walks = lambda k: t[k]["rays"] - t[k]["inline_shadow_rays"] if k in t else 0
+        assert walks("k_primary") == fif * W * H
+        st2 = walks("k_primary2") + walks("k_primary2c")
         assert st2 == deferred[0]
         assert ("k_primary2" in t) != ("k_primary2c" in t) or deferred[0] == 0
         assert t["k_primary"]["record_bytes"] >= 16 * (fif * W * H - deferred[0])  # a pixel or a frame record per finished pixel
@@ -1270,3 +1272,56 @@ def test_plane_coverage_masks_in_awkward_views(pkg, orc, tmp_path):
             assert np.array_equal(out[i].view(np.uint32), refs[i].view(np.uint32)), "batch: view %d differs" % i
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["teapot2_240x135", "p11_240x135", "p4_240x135", "p7_200x150", "p13_200x150", "mtl_160x120"])
+def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
+    """Round 3: a Shade() call that fires no secondary ray (mtlFunctions.cpp:125-155 and nothing else) is settled by the lane that
+    found the hit — its shadow rays through the occluder lists, its light loop — and never becomes a frame record
+    (render_impl.h shadows_inline). rtu_debug_flags 2048 switches that off: every image must be the same bit for bit (one frame,
+    frames in flight, both stage-2 forms), the level-0 frame count must drop, and the counting variant — which always materialises
+    every call — must agree with both."""
+    g = golden(tag)
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    cnt, _ = ctx.render(pkg.frame_setup(scene.desc.camera, W, H, collect_stats=True), stats=True)
+    cams = []
+    for i in range(3):
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        cam.pos[0] += 0.3 * i
+        cams.append(cam)
+    d = pkg.hip.rtu_device_alloc(ctx._h, 3 * W * H * 16)
+    res = {}
+    try:
+        for flags in (0, 2048):
+            pkg.hip.rtu_debug_flags(ctx._h, flags)
+            for coop in (1, 10 ** 9):
+                fr = pkg.frame_setup(scene.desc.camera, W, H)
+                fr.coop_threshold = coop
+                img, _ = ctx.render(fr)
+                assert np.array_equal(img.view(np.uint32), cnt.view(np.uint32)), "flags %d, threshold %d: differs from the counting variant" % (flags, coop)
+                frames, _ = ctx.frame_counts()
+                res[(flags, coop)] = frames[0]
+                fs = [pkg.frame_setup(c, W, H) for c in cams]
+                for f in fs:
+                    f.coop_threshold = coop
+                for attempt in range(8):  # (a level may have to grow its frame records first: rtu_frame_status says so, render again)
+                    ctx.render_frames_device(fs, d, None)
+                    try:
+                        ctx.frame_status()
+                        break
+                    except pkg.RtuError as e:
+                        if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                            raise
+                out = np.empty((3, H, W, 4), np.float32)
+                assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+                res[(flags, coop, "batch")] = out
+        for coop in (1, 10 ** 9):
+            assert np.array_equal(res[(0, coop, "batch")].view(np.uint32), res[(2048, coop, "batch")].view(np.uint32))
+            assert res[(0, coop)] <= res[(2048, coop)]
+            if tag in ("teapot2_240x135", "p11_240x135"):  # (scenes whose every material reflects or refracts have no childless call)
+                assert res[(0, coop)] < res[(2048, coop)], "no Shade() call was settled without a frame (%d vs %d level-0 frames)" % (res[(0, coop)], res[(2048, coop)])
+    finally:
+        pkg.hip.rtu_debug_flags(ctx._h, 0)
+        pkg.hip.rtu_device_free(ctx._h, d)

@@ -505,7 +505,9 @@ def test_frame_capacity_overflow_is_detected_and_repaired(pkg, orc, tmp_path):
         pkg.hip.rtu_device_free(ctx._h, d)
         check_against(out, cpu, orc)
         frames, _ = ctx.frame_counts()
-        assert frames[1] > W * H, frames  # more child frames than pixels: the case the test is about
+        # more child frames than pixels in some level: the case the test is about (the wall seen through and in the ball is
+        # childless — settled without a frame since round 3 —, the ball's own inside keeps multiplying)
+        assert max(frames[1:]) > W * H, frames
     finally:
         ctx.close()
     ctx2 = pkg.Context(0)  # synchronous entry on a fresh context: transparent retry
@@ -724,8 +726,10 @@ def test_touched_bytes_mode_is_the_fast_variant_counting_itself(pkg, ctx, golden
         assert t["k_primary"]["record_bytes"] >= 16 * (fif * W * H - deferred[0])  # a pixel or a frame record per finished pixel
         for name, c in t.items():
             assert c["bytes"] >= c["record_bytes"] and c["bytes"] > 0, name
-            if name.startswith(("k_consume", "k_combine")):
+            if name.startswith("k_combine"):
                 assert c["rays"] == 0 and c["bytes"] == c["record_bytes"]
+            if name.startswith("k_consume"):  # (the only rays it fires are the shadow rays of the childless children it settles itself)
+                assert c["rays"] == c["inline_shadow_rays"]
             if name.startswith("k_trace2(") or name == "k_primary2":
                 assert c["inner8"] == 0
             if name.startswith("k_trace2c") or name == "k_primary2c":

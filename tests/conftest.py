@@ -32,8 +32,9 @@ def instantiate_scene(rel, dst):
             data = data.replace(b"@DIR@", str(dst).encode())
         open(os.path.join(str(dst), name), "wb").write(data)
     return os.path.join(str(dst), os.path.basename(rel))
-# stochastic effects, recipe S: glossy + soft + textured; depth of field; glossy + soft; 12 soft lights + glossy refraction; teapot + soft
-SAMPLED_TAGS = ["p10_s4_160x120", "p9_s3_160x120", "p11gs_s2_160x90", "p11x86_s1_120x90", "teapot1_s2_160x90"]
+# stochastic effects, recipe S: glossy + soft + textured; depth of field; glossy + soft; 12 soft lights + glossy refraction; teapot + soft;
+# glossy under a hard light (Project11/scene_glossy.xml: with it every scene file of the reference has a fixture)
+SAMPLED_TAGS = ["p10_s4_160x120", "p9_s3_160x120", "p11gs_s2_160x90", "p11x86_s1_120x90", "teapot1_s2_160x90", "p11g_s2_160x90"]
 PATH_TAGS = ["p11_p2_120x68", "p13_p2_96x72"]  # recipe P (config 5): + the Monte-Carlo gather
 
 

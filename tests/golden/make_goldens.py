@@ -54,6 +54,8 @@ CONFIGS = [
     ("p11gs_s2_160x90", "Project11/scene_glossy_soft.xml", 160, 90, True, 2),
     ("p11x86_s1_120x90", "Project11/scene_86.xml", 120, 90, True, 1),
     ("teapot1_s2_160x90", "Teapot/scene.xml", 160, 90, True, 2),
+    # the last scene file of the reference without a fixture (round 3): glossy reflections under a hard point light
+    ("p11g_s2_160x90", "Project11/scene_glossy.xml", 160, 90, True, 2),
     # row f3: an .obj that brings its own materials (usemtl / .mtl -> MultiMtl, xmlload.cpp:199-243) — a scene written for
     # this repository (tests/scenes/multimtl, "@" = repository path), run through the compiled reference like the others
     ("mtl_160x120", "@tests/scenes/multimtl/scene.xml", 160, 120, True),

@@ -22,7 +22,7 @@ SCENES = {
     "p7_200x150": "Project7/scene.xml",
     "p10_s4_160x120": "Project10/scene.xml", "p9_s3_160x120": "Project9/scene.xml",
     "p11gs_s2_160x90": "Project11/scene_glossy_soft.xml", "p11x86_s1_120x90": "Project11/scene_86.xml",
-    "teapot1_s2_160x90": "Teapot/scene.xml",
+    "teapot1_s2_160x90": "Teapot/scene.xml", "p11g_s2_160x90": "Project11/scene_glossy.xml",
 }
 
 

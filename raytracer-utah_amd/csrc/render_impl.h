@@ -1388,8 +1388,13 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
 // the gather ray if it missed (:575), or 0.1 at the last bounce (:584). This kernel computes c for every
 // chain that has a hit of depth a.gi_depth and appends the two Shade() trees of that hit as level-0 frames.
 // inline_ok: the fast variant (the counting variant materialises every Shade() call as a frame: its counters are the reference's).
+#ifndef RTU_OCC_GI_ROOTS
+// k_gi_roots settles the childless Shade() calls of recipe P itself (shadow rays, light loop): left alone it takes 140 VGPRs and fits three
+// wavefronts per SIMD (2578 us per launch of 33 M chains); four: 2191 us; five (41 registers spilled): 3116 us
+#define RTU_OCC_GI_ROOTS __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <int TEX>
-__global__ void __launch_bounds__(64) k_gi_roots(KernelArgs a, int inline_ok) {
+__global__ void __launch_bounds__(64) RTU_OCC_GI_ROOTS k_gi_roots(KernelArgs a, int inline_ok) {
     const DevScene& s = a.scene;
     const uint32_t lane = threadIdx.x;
     const uint32_t k = a.gi_depth;

@@ -1153,7 +1153,8 @@ int render_sampled(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hi
     const size_t pixels = (size_t)rtu_shard_rows(frame) * (size_t)frame->width;
     if (pixels == 0) return RTU_OK;
     const bool gi = frame->gather_bounces != 0;
-    int batch = (int)(((size_t)1 << (gi ? 23 : 25)) / pixels);  // recipe P keeps 22 float4 per chain and two roots per chain hit (a larger batch buys nothing: measured)
+    static const int kGiLog2 = [] { const char* e = getenv("RTU_GI_BATCH_LOG2"); return e ? atoi(e) : 25; }();  // tuning knob (23 / 24 / 25: 138.2 / 131.9 / 130.6 ms for config 5 at 64 spp)
+    int batch = (int)(((size_t)1 << (gi ? kGiLog2 : 25)) / pixels);  // recipe P keeps 22 float4 per chain and two roots per chain hit (a larger batch buys nothing: measured)
     if (batch > RTU_MAX_BATCH) batch = RTU_MAX_BATCH;
     if (batch > frame->samples) batch = frame->samples;
     if (batch < 1) batch = 1;

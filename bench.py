@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--rays-per-frame", type=int, default=0,
                     help="diagnostic only: skip the (slow, untimed) counting pass that counts the reference's rays per frame and use this number instead — "
                          "for profiler runs of sampled frames, where the counting variant would drown the timed kernels in the trace")
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="N=1: launch sequences alternate over this many contexts, each on a stream of its own (default 2): the latency-bound recursion "
+                         "levels of one sequence overlap the primary kernels of the next. Only when the timed region holds at least that many full "
+                         "batches (the driver's --steps 20 is one batch: one context)")
     ap.add_argument("--same-camera", action="store_true", help="diagnostic only: every frame of a batch from the golden camera (no turntable)")
     ap.add_argument("--samples", type=int, default=0,
                     help="diagnostic only: S >= 1 renders recipe S (S samples per pixel; soft shadows, glossy bounces, depth of field) — "
@@ -225,12 +229,26 @@ def main():
             gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
     shard = shards[0]
     stream = torch.cuda.current_stream().cuda_stream
+    # N = 1: C contexts, each with its own stream and image buffer; batch i goes to context i mod C. Two launch sequences in flight:
+    # the deep recursion levels of one (small, latency-bound kernels) overlap the primary kernels of the other (instruction-bound)
+    C = 1
+    if world == 1 and not sampled and args.contexts > 1 and args.steps >= args.contexts * B and B > 1:
+        C = args.contexts
+    ctxs, tstreams = [ctx], [torch.cuda.current_stream()]
+    for _ in range(C - 1):
+        c2 = pkg.Context(local_rank)
+        c2.upload(scene)
+        if args.dbg:
+            pkg.hip.rtu_debug_flags(c2._h, args.dbg)
+        ctxs.append(c2)
+        tstreams.append(torch.cuda.Stream(device=dev))
+        shards.append(torch.zeros_like(shards[0]))
 
-    def launch(frs, buf):
+    def launch(frs, buf, k=0):
         if len(frs) == 1:
-            ctx.render_device(frs[0], buf.data_ptr(), stream)
+            ctxs[k].render_device(frs[0], buf.data_ptr(), tstreams[k].cuda_stream)
         else:
-            ctx.render_frames_device(frs, buf.data_ptr(), stream)
+            ctxs[k].render_frames_device(frs, buf.data_ptr(), tstreams[k].cuda_stream)
 
     # -- untimed: rays of every camera of the turntable (this shard), from the counting variant -------------
     if sampled:  # settle the frame-record capacities first: the counting pass of a sampled frame does not re-provision
@@ -288,16 +306,17 @@ def main():
             if ev:
                 ev[1].record()
             return
-        buf = pipe.begin(i) if pipe else shard  # waits (on the GPU) for the gather that last read this buffer
+        k = i % C
+        buf = pipe.begin(i) if pipe else shards[k]  # waits (on the GPU) for the gather that last read this buffer
         if packed:
             send, buf = buf, shards[i & 1]
         if ev:
-            ev[0].record()
-        launch(frames[:nb], buf)
+            ev[0].record(tstreams[k])
+        launch(frames[:nb], buf, k)
         if packed:  # z of the nb frames, then their Color24 pixels (sharding.assemble_gathered_packed reads this layout)
             ctx.pack_image_device(buf.data_ptr(), nb * rows * W, send.data_ptr(), send.data_ptr() + B * max_rows * W * 4, stream)
         if ev:
-            ev[1].record()
+            ev[1].record(tstreams[k])
         if pipe:
             pipe.gather(i)  # RCCL over xGMI, asynchronous: overlaps the next batch's kernels
 
@@ -309,19 +328,20 @@ def main():
             if pipe:
                 pipe.drain()
             settled = 1
-            try:
-                ctx.frame_status()
-            except pkg.RtuError as e:
-                if e.code != pkg.RTU_ERR_CAPACITY or attempt == 2 * 6:
-                    raise
-                settled = 0
+            for cx in ctxs:
+                try:
+                    cx.frame_status()
+                except pkg.RtuError as e:
+                    if e.code != pkg.RTU_ERR_CAPACITY or attempt == 2 * 6:
+                        raise
+                    settled = 0
             if dist:
                 flag = torch.tensor([settled], dtype=torch.int32, device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 settled = int(flag[0])
             if settled:
                 return
-    settle(lambda: [step(j, B) for j in range(max(1, -(-args.warmup // B)))])  # warm-up at the full batch size (>= args.warmup frames)
+    settle(lambda: [step(j, B) for j in range(max(C, -(-args.warmup // B)))])  # warm-up at the full batch size (>= args.warmup frames; every context at least once)
 
     # -- untimed: what every kernel of the launch sequence touches (the fast variant counting itself) and how long it lasts
     # (a sampled frame is many launch sequences — one per batch of samples, ten per batch for recipe P —: its counters are sums over
@@ -385,7 +405,8 @@ def main():
     gathered = pipe.last_gathered() if pipe else None
     dom_ms = dom_sum / max(dom_n, 1) if dominant else None
     kernel_ms = float(np.mean(seq_ms))
-    ctx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
+    for cx in ctxs:
+        cx.frame_status()  # raises if a recursion level overflowed its provisioned capacity
     rays_total = sum(rays_of[j] for nb in batches for j in range(nb))
 
     seq_bytes = float(sum(k["bytes_per_frame"] for k in kernels.values()))  # of one launch sequence (recipe W) / of all sequences of one frame (sampled)
@@ -497,6 +518,7 @@ def main():
                        "cameras": "one per frame of a batch: the scene's camera orbited by %g degrees per frame (frame 0 = the golden camera)" % ORBIT_STEP_DEG
                                   if len(set(rays_of)) > 1 or not (args.same_camera or sampled) else "the scene's camera for every frame",
                        "batch_latency_ms": round(kernel_ms, 4),  # HIP-event time of ONE launch sequence of frames_in_flight frames
+                       "launch_sequences_in_flight": C,  # contexts / streams the batches alternate over (two: the deep levels of one sequence overlap the primary kernels of the next)
                        "repeats": {"n": R, "region_ms_median": round(elapsed * 1e3, 4), "region_ms_min": round(min(region_s) * 1e3, 4),
                                    "region_ms_max": round(max(region_s) * 1e3, 4), "region_ms_first": round(region_s[0] * 1e3, 4),
                                    "timed_ms_total": round(sum(region_s) * 1e3, 2),
@@ -511,7 +533,8 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(g, scene, W, H, rays_of[0], args.cpu_seconds, args.cpu_threads, args.samples, args.paths)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
     if dist:
         dist.destroy_process_group()
 

@@ -1,7 +1,7 @@
 """Experiment: the driver's bench call renders 20 frames once (--steps 20). One launch sequence of 20, or K sequences of 20/K on K
 streams (K contexts): wall time from the first launch to the last kernel done, best and median of 15 repetitions."""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 import __graft_entry__ as g
 import bench

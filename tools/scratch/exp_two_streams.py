@@ -1,7 +1,7 @@
 """Experiment: K contexts on one GPU, each on its own stream, each with B frames in flight, launched alternately —
 do the latency-bound deep levels of one launch sequence overlap the wide kernels of another?"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import __graft_entry__ as g
 import bench

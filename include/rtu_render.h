@@ -289,6 +289,22 @@ int  rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5);
  * cells together, entries of the longest cell}. RTU_ERR_ARG past the last one. */
 int  rtu_light_list_info(const RtuContext* ctx, uint32_t index, uint32_t* out5);
 
+/* Test hook, pure host code (no GPU, no context): the occluder list rtu_upload_scene would build for the light_slot-th non-ambient
+ * light and the cover_slot-th mesh node of the scene — frame, grid and, per cell, its entries as FACES of the node's mesh with the
+ * depth in front of which an origin cannot see them (ascending per cell) — so that a CPU test can check ray by ray that every
+ * triangle a shadow ray hits is listed in the cell of the ray's origin. cell = int((v - v0) * sv) * G + int((u - u0) * su) with
+ * (u, v) = ((p - L) . X, (p - L) . Y) [/ ((p - L) . Z) for a point light]. usable == 0: no list from there (arrays NULL). */
+typedef struct RtuLightListDump {
+    int32_t  usable, node, light;
+    uint32_t G, point, n_entries;
+    float    X[3], Y[3], Z[3], L[3], u0, v0, su, sv;
+    uint32_t* cell_off;     /* [G * G + 1] */
+    uint32_t* entry_face;   /* [n_entries] */
+    float*    entry_zmin;   /* [n_entries] */
+} RtuLightListDump;
+int  rtu_debug_light_list(const RtuSceneDesc* scene, uint32_t light_slot, uint32_t cover_slot, RtuLightListDump* out);
+void rtu_debug_light_list_free(RtuLightListDump* dump);
+
 /* Diagnostic: Shade() frames per recursion level (6 values) and rays deferred to stage 2 per phase
  * (7 values: primary, then levels 0..5) of the most recent frame (fast variant). Synchronises. */
 int  rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_out);

@@ -142,7 +142,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_get_touched_launches", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_light_list", "rtu_debug_light_list_free", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_get_touched_launches", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host", "rtu_device_info", "rtu_set_cancel_flag", "rtu_create_context_multi", "rtu_destroy_context_multi",
                "rtu_multi_size", "rtu_multi_context", "rtu_multi_last_error", "rtu_multi_upload_scene", "rtu_multi_render_frame", "rtu_multi_gather_kind"]
 _sig(hip, "rtu_device_count", _I)
@@ -210,6 +210,37 @@ _sig(hip, "rtu_multi_last_error", ctypes.c_char_p, _P)
 _sig(hip, "rtu_multi_upload_scene", _I, _P, _P)
 _sig(hip, "rtu_multi_render_frame", _I, _P, ctypes.POINTER(RtuFrameDesc), _P, ctypes.POINTER(RtuProgress))
 _sig(hip, "rtu_multi_gather_kind", _I, _P)
+
+
+class RtuLightListDump(ctypes.Structure):
+    _fields_ = [("usable", ctypes.c_int32), ("node", ctypes.c_int32), ("light", ctypes.c_int32), ("G", ctypes.c_uint32), ("point", ctypes.c_uint32),
+                ("n_entries", ctypes.c_uint32), ("X", ctypes.c_float * 3), ("Y", ctypes.c_float * 3), ("Z", ctypes.c_float * 3), ("L", ctypes.c_float * 3),
+                ("u0", ctypes.c_float), ("v0", ctypes.c_float), ("su", ctypes.c_float), ("sv", ctypes.c_float),
+                ("cell_off", ctypes.POINTER(ctypes.c_uint32)), ("entry_face", ctypes.POINTER(ctypes.c_uint32)), ("entry_zmin", ctypes.POINTER(ctypes.c_float))]
+
+
+_sig(hip, "rtu_debug_light_list", _I, _P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(RtuLightListDump))
+_sig(hip, "rtu_debug_light_list_free", None, ctypes.POINTER(RtuLightListDump))
+
+
+def light_list(scene, light_slot, cover_slot):
+    """Pure host code: the occluder list of (non-ambient light, mesh node) as numpy arrays, or None when no list is usable from there:
+    dict(G, point, X, Y, Z, L, u0, v0, su, sv, node, light, cell_off [G*G+1], entry_face, entry_zmin)."""
+    import numpy as np
+    d = RtuLightListDump()
+    rc = hip.rtu_debug_light_list(scene.desc_ptr, light_slot, cover_slot, ctypes.byref(d))
+    if rc != RTU_OK:
+        raise RtuError(rc, "rtu_debug_light_list")
+    try:
+        if not d.usable:
+            return None
+        n = d.G * d.G + 1
+        return {"G": d.G, "point": bool(d.point), "X": np.array(list(d.X)), "Y": np.array(list(d.Y)), "Z": np.array(list(d.Z)), "L": np.array(list(d.L)),
+                "u0": d.u0, "v0": d.v0, "su": d.su, "sv": d.sv, "node": d.node, "light": d.light,
+                "cell_off": np.ctypeslib.as_array(d.cell_off, (n,)).copy(), "entry_face": np.ctypeslib.as_array(d.entry_face, (max(d.n_entries, 1),))[:d.n_entries].copy(),
+                "entry_zmin": np.ctypeslib.as_array(d.entry_zmin, (max(d.n_entries, 1),))[:d.n_entries].copy()}
+    finally:
+        hip.rtu_debug_light_list_free(ctypes.byref(d))
 
 
 def device_info(device_id=0):

@@ -530,22 +530,21 @@ struct CoverMesh {
     std::vector<double> verts;      // per face: 3 world-space vertices (9 doubles)
     std::vector<uint32_t> slot_of;  // face -> slot in the leaf order of the mesh's fast tree
 };
-int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<CoverMesh>& cover, float wscale, DevScene& ds) {
-    ds.lmask = nullptr;
-    std::vector<uint32_t> lights;
-    for (uint32_t i = 0; i < s->n_lights && lights.size() < RTU_LMASK_LIGHTS; i++)
-        if (s->lights[i].type != RTU_LIGHT_AMBIENT) lights.push_back(i);
-    const uint32_t nc = (uint32_t)cover.size();
-    if (lights.empty() || nc == 0) return RTU_OK;
-    std::vector<DevLightMask> masks(lights.size() * nc);
-    memset(masks.data(), 0, masks.size() * sizeof(DevLightMask));
+// One list: pure host arithmetic (no GPU) — the frame, the grid and the cells' entries {slot, zmin bits} of light `l` looking at the mesh
+// `cm`. false: no usable list from there. (rtu_debug_light_list hands the result to the CPU tests, which check it ray by ray.)
+struct HostLightList {
+    DevLightMask m;                 // frame, offsets, scale, G, point (the device pointers stay null here)
+    std::vector<uint32_t> off, ent;
+};
+bool compute_light_list(const RtuLight& l, const CoverMesh& cm, float wscale, HostLightList& out) {
+    DevLightMask& m = out.m;
+    memset(&m, 0, sizeof m);
+    std::vector<uint32_t>& off = out.off;
+    std::vector<uint32_t>& ent = out.ent;
     const double r3 = 1.7320508075688772;
-    for (size_t j = 0; j < lights.size(); j++) {
-        const RtuLight& l = s->lights[lights[j]];
-        const bool point = l.type == RTU_LIGHT_POINT;
-        for (uint32_t c = 0; c < nc; c++) {
-            DevLightMask& m = masks[j * nc + c];
-            const std::vector<float4>& boxes = cover[c].boxes;
+    const bool point = l.type == RTU_LIGHT_POINT;
+    {
+    const std::vector<float4>& boxes = cm.boxes;
             const size_t nf = boxes.size() / 2;
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (size_t f = 0; f < nf; f++) {
@@ -560,7 +559,7 @@ int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                 for (int k = 0; k < 3; k++) Z[k] = l.vec[k];
             }
             const double zl = std::sqrt(Z[0] * Z[0] + Z[1] * Z[1] + Z[2] * Z[2]);
-            if (!(zl > 0) || !std::isfinite(zl)) continue;  // unusable
+            if (!(zl > 0) || !std::isfinite(zl)) return false;  // unusable
             for (int k = 0; k < 3; k++) Z[k] /= zl;
             int ax = std::fabs(Z[0]) <= std::fabs(Z[1]) ? (std::fabs(Z[0]) <= std::fabs(Z[2]) ? 0 : 2) : (std::fabs(Z[1]) <= std::fabs(Z[2]) ? 1 : 2);
             double A[3] = {0, 0, 0};
@@ -595,13 +594,12 @@ int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                     U0 = std::min(U0, u); U1 = std::max(U1, u); V0 = std::min(V0, v); V1 = std::max(V1, v);
                 }
             }
-            if (!ok || !(U1 > U0) || !(V1 > V0)) continue;
+            if (!ok || !(U1 > U0) || !(V1 > V0)) return false;
             const double mag = std::max(std::max(std::fabs(U0), std::fabs(U1)), std::max(std::fabs(V0), std::fabs(V1)));
-            if (!std::isfinite(mag) || (U1 - U0) < 1e-4 * mag || (V1 - V0) < 1e-4 * mag) continue;  // no extent a float lookup could resolve
+            if (!std::isfinite(mag) || (U1 - U0) < 1e-4 * mag || (V1 - V0) < 1e-4 * mag) return false;  // no extent a float lookup could resolve
             // grid size: a triangle of an evenly tessellated surface spans ~ G / sqrt(nf / 2) cells; aim at six of them
             uint32_t G = 64;
             while (G < RTU_LGRID_MAX && (double)G < 6.0 * std::sqrt((double)nf * 0.5)) G *= 2;
-            std::vector<uint32_t> off, ent;
             for (;; G /= 2) {
                 if (G < 16u) { ok = false; break; }
                 // the grid spans the extent plus two cells on every side
@@ -623,7 +621,7 @@ int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                         ent.assign(2 * total, 0u);
                     }
                     for (size_t f = 0; f < nf; f++) {
-                        const double* w = cover[c].verts.data() + 9 * f;
+                        const double* w = cm.verts.data() + 9 * f;
                         double pu[3], pv[3], dmin = 1e300, umax = 0, vmax = 0;
                         for (int k = 0; k < 3; k++) {
                             const double q[3] = {w[3 * k] - L[0], w[3 * k + 1] - L[1], w[3 * k + 2] - L[2]};
@@ -658,7 +656,7 @@ int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                             nx[i] = sg * ey; ny[i] = -sg * ex;  // outward for a counter-clockwise triangle (area2 > 0)
                             nd[i] = (std::fabs(nx[i]) + std::fabs(ny[i])) * (0.5 + S);
                         }
-                        const uint32_t slot = cover[c].slot_of[f];
+                        const uint32_t slot = cm.slot_of[f];
                         // the depth (along Z) in front of which an origin cannot see this triangle at all — every point of it, the cull
                         // margin and the rounding of the device's own depth included, lies beyond (entries are sorted by it)
                         double zmin = 1e300;
@@ -703,17 +701,62 @@ int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<
                 m.G = G;
                 break;
             }
-            if (!ok) continue;
-            int rc;
-            if ((rc = upload(ctx, off.data(), off.size(), &m.cell_off)) != RTU_OK) return rc;
-            if ((rc = upload(ctx, ent.data(), ent.size(), &m.cell_tri)) != RTU_OK) return rc;
-            m.usable = 1u;
-            ctx->light_list_info.push_back({(uint32_t)j, c, m.G, (uint32_t)(ent.size() / 2), 0u});
-            uint32_t longest = 0;
-            for (size_t i = 0; i < (size_t)m.G * m.G; i++) longest = std::max(longest, off[i + 1] - off[i]);
-            ctx->light_list_info.back().longest = longest;
-        }
+            if (!ok) return false;
     }
+    m.usable = 1u;
+    return true;
+}
+
+// The triangles of mesh node `node` in world space: every vertex through the chain p -> tm p + pos in binary64; per face its three
+// vertices and their box rounded outwards. fast_elements: slot of the mesh's fast tree -> face.
+void make_cover_mesh(const RtuSceneDesc* s, uint32_t node, const std::vector<uint32_t>& fast_elements, CoverMesh& cm) {
+    const RtuMesh& m = s->meshes[s->nodes[node].mesh_id];
+    cm.boxes.assign((size_t)m.nf * 2, make_float4(0, 0, 0, 0));
+    cm.verts.assign((size_t)m.nf * 9, 0.0);
+    for (uint32_t f = 0; f < m.nf; f++) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int v = 0; v < 3; v++) {
+            const float* lp = m.v + 3 * (size_t)m.f[3 * (size_t)f + v];
+            double p[3] = {lp[0], lp[1], lp[2]};
+            for (int j = (int)node; j >= 0; j = s->nodes[j].parent) {
+                const RtuNode& t = s->nodes[j];
+                const double q[3] = {p[0] * t.tm[0] + p[1] * t.tm[3] + p[2] * t.tm[6] + t.pos[0], p[0] * t.tm[1] + p[1] * t.tm[4] + p[2] * t.tm[7] + t.pos[1],
+                                     p[0] * t.tm[2] + p[1] * t.tm[5] + p[2] * t.tm[8] + t.pos[2]};
+                p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+            }
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); cm.verts[9 * (size_t)f + 3 * v + k] = p[k]; }
+        }
+        cm.boxes[2 * (size_t)f] = make_float4(std::nextafter((float)lo[0], -INFINITY), std::nextafter((float)lo[1], -INFINITY), std::nextafter((float)lo[2], -INFINITY), 0.0f);
+        cm.boxes[2 * (size_t)f + 1] = make_float4(std::nextafter((float)hi[0], INFINITY), std::nextafter((float)hi[1], INFINITY), std::nextafter((float)hi[2], INFINITY), 0.0f);
+    }
+    cm.slot_of.assign(m.nf, 0u);
+    for (uint32_t sl = 0; sl < (uint32_t)fast_elements.size(); sl++) cm.slot_of[fast_elements[sl]] = sl;
+}
+
+int build_light_lists(RtuContext* ctx, const RtuSceneDesc* s, const std::vector<CoverMesh>& cover, float wscale, DevScene& ds) {
+    ds.lmask = nullptr;
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < s->n_lights && lights.size() < RTU_LMASK_LIGHTS; i++)
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT) lights.push_back(i);
+    const uint32_t nc = (uint32_t)cover.size();
+    if (lights.empty() || nc == 0) return RTU_OK;
+    std::vector<DevLightMask> masks(lights.size() * nc);
+    memset(masks.data(), 0, masks.size() * sizeof(DevLightMask));
+    for (size_t j = 0; j < lights.size(); j++)
+        for (uint32_t c = 0; c < nc; c++) {
+            HostLightList hl;
+            if (!compute_light_list(s->lights[lights[j]], cover[c], wscale, hl)) continue;
+            DevLightMask& m = masks[j * nc + c];
+            m = hl.m;
+            m.usable = 0u;
+            int rc;
+            if ((rc = upload(ctx, hl.off.data(), hl.off.size(), &m.cell_off)) != RTU_OK) return rc;
+            if ((rc = upload(ctx, hl.ent.data(), hl.ent.size(), &m.cell_tri)) != RTU_OK) return rc;
+            m.usable = 1u;
+            uint32_t longest = 0;
+            for (size_t i = 0; i < (size_t)m.G * m.G; i++) longest = std::max(longest, hl.off[i + 1] - hl.off[i]);
+            ctx->light_list_info.push_back({(uint32_t)j, c, m.G, (uint32_t)(hl.ent.size() / 2), longest});
+        }
     return upload(ctx, masks.data(), masks.size(), &ds.lmask);
 }
 
@@ -1499,33 +1542,10 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
             ds.cover_node[ds.n_cover++] = (int32_t)i;
             const RtuMesh& m = s->meshes[s->nodes[i].mesh_id];
             if (m.nf > ctx->cover_faces) ctx->cover_faces = m.nf;
-            // world-space box of every triangle: vertices through the chain p -> tm p + pos in binary64, rounded outwards
-            std::vector<float4> boxes((size_t)m.nf * 2);
-            std::vector<double> verts((size_t)m.nf * 9);
-            for (uint32_t f = 0; f < m.nf; f++) {
-                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                for (int v = 0; v < 3; v++) {
-                    const float* lp = m.v + 3 * (size_t)m.f[3 * (size_t)f + v];
-                    double p[3] = {lp[0], lp[1], lp[2]};
-                    for (int j = (int)i; j >= 0; j = s->nodes[j].parent) {
-                        const RtuNode& t = s->nodes[j];
-                        const double q[3] = {p[0] * t.tm[0] + p[1] * t.tm[3] + p[2] * t.tm[6] + t.pos[0], p[0] * t.tm[1] + p[1] * t.tm[4] + p[2] * t.tm[7] + t.pos[1],
-                                             p[0] * t.tm[2] + p[1] * t.tm[5] + p[2] * t.tm[8] + t.pos[2]};
-                        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
-                    }
-                    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); verts[9 * (size_t)f + 3 * v + k] = p[k]; }
-                }
-                boxes[2 * (size_t)f] = make_float4(std::nextafter((float)lo[0], -INFINITY), std::nextafter((float)lo[1], -INFINITY), std::nextafter((float)lo[2], -INFINITY), 0.0f);
-                boxes[2 * (size_t)f + 1] = make_float4(std::nextafter((float)hi[0], INFINITY), std::nextafter((float)hi[1], INFINITY), std::nextafter((float)hi[2], INFINITY), 0.0f);
-            }
-            if ((rc = upload(ctx, boxes.data(), boxes.size(), &ds.cover_box[ds.n_cover - 1])) != RTU_OK) return rc;
-            ds.cover_nf[ds.n_cover - 1] = m.nf;
             CoverMesh cm;
-            cm.boxes = std::move(boxes);
-            cm.verts = std::move(verts);
-            cm.slot_of.assign(m.nf, 0u);
-            const std::vector<uint32_t>& el = fast_elements[s->nodes[i].mesh_id];
-            for (uint32_t sl = 0; sl < (uint32_t)el.size(); sl++) cm.slot_of[el[sl]] = sl;
+            make_cover_mesh(s, i, fast_elements[s->nodes[i].mesh_id], cm);
+            if ((rc = upload(ctx, cm.boxes.data(), cm.boxes.size(), &ds.cover_box[ds.n_cover - 1])) != RTU_OK) return rc;
+            ds.cover_nf[ds.n_cover - 1] = m.nf;
             cover_host.push_back(std::move(cm));
         }
     }
@@ -1981,6 +2001,54 @@ int rtu_mesh_info(const RtuContext* ctx, uint32_t mesh, uint32_t* out5) {
     const RtuContext::MeshInfo& i = ctx->mesh_info[mesh];
     out5[0] = i.faces; out5[1] = i.sah_depth; out5[2] = i.stack4; out5[3] = i.nodes4; out5[4] = i.nodes8;
     return RTU_OK;
+}
+
+int rtu_debug_light_list(const RtuSceneDesc* s, uint32_t light_slot, uint32_t cover_slot, RtuLightListDump* out) {
+    if (!out) return RTU_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    RtuContext tmp;  // plain host state: nothing here touches a GPU
+    int rc = validate(&tmp, s);
+    if (rc != RTU_OK) return rc;
+    int li = -1, node = -1;
+    uint32_t seen = 0;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+        if (s->lights[i].type != RTU_LIGHT_AMBIENT && seen++ == light_slot) { li = (int)i; break; }
+    seen = 0;
+    for (uint32_t i = 0; i < s->n_nodes && i < 64u; i++)
+        if (s->nodes[i].obj_type == RTU_OBJ_TRIMESH && seen++ == cover_slot) { node = (int)i; break; }
+    if (li < 0 || node < 0) return RTU_ERR_ARG;
+    std::vector<DevNode> nodes(s->n_nodes);
+    const float wscale = world_bounds(s, nodes);
+    SahTree sah;
+    build_sah(s->meshes[s->nodes[node].mesh_id], sah);
+    CoverMesh cm;
+    make_cover_mesh(s, (uint32_t)node, sah.elements, cm);
+    HostLightList hl;
+    out->node = node;
+    out->light = li;
+    if (!compute_light_list(s->lights[li], cm, wscale, hl)) return RTU_OK;  // usable == 0
+    out->usable = 1;
+    out->G = hl.m.G;
+    out->point = hl.m.point;
+    memcpy(out->X, hl.m.X, sizeof out->X); memcpy(out->Y, hl.m.Y, sizeof out->Y); memcpy(out->Z, hl.m.Z, sizeof out->Z); memcpy(out->L, hl.m.L, sizeof out->L);
+    out->u0 = hl.m.u0; out->v0 = hl.m.v0; out->su = hl.m.su; out->sv = hl.m.sv;
+    out->n_entries = (uint32_t)(hl.ent.size() / 2);
+    out->cell_off = (uint32_t*)malloc(hl.off.size() * sizeof(uint32_t));
+    out->entry_face = (uint32_t*)malloc((hl.ent.size() / 2 + 1) * sizeof(uint32_t));
+    out->entry_zmin = (float*)malloc((hl.ent.size() / 2 + 1) * sizeof(float));
+    if (!out->cell_off || !out->entry_face || !out->entry_zmin) { rtu_debug_light_list_free(out); return RTU_ERR_ARG; }
+    memcpy(out->cell_off, hl.off.data(), hl.off.size() * sizeof(uint32_t));
+    for (size_t e = 0; e < hl.ent.size() / 2; e++) {
+        out->entry_face[e] = sah.elements[hl.ent[2 * e]];  // slot of the fast tree -> face of the mesh
+        memcpy(&out->entry_zmin[e], &hl.ent[2 * e + 1], 4);
+    }
+    return RTU_OK;
+}
+
+void rtu_debug_light_list_free(RtuLightListDump* d) {
+    if (!d) return;
+    free(d->cell_off); free(d->entry_face); free(d->entry_zmin);
+    d->cell_off = nullptr; d->entry_face = nullptr; d->entry_zmin = nullptr;
 }
 
 int rtu_light_list_info(const RtuContext* ctx, uint32_t index, uint32_t* out5) {

@@ -266,11 +266,12 @@ int  rtu_debug_tail_from(RtuContext* ctx, int level);
 int  rtu_debug_node_bounds(RtuContext* ctx, int on);
 
 /* Experiment switches for performance work (which part of a kernel costs what): bits are defined next to their use in
- * render_impl.h; bits 0..7 render WRONG images: never set them in production paths or tests of results. Four bits only switch an
+ * render_impl.h; bits 0..7 render WRONG images: never set them in production paths or tests of results. Five bits only switch an
  * optimisation off and leave every result bit alone (tests compare the images with and without): 256 = no tile occupancy
  * (k_primary tests every tile against the node rectangles and coverage masks itself), 512 = no stage-2 grid hints (both
  * stage-2 kernels of every tracing phase are launched at full size), 64 = the occluder lists of shadow rays only say "empty cell or
- * not" (every listed ray walks the BVH), 2048 = no Shade() call is settled without a frame record (every hit becomes a frame). */
+ * not" (every listed ray walks the BVH), 2048 = no Shade() call is settled without a frame record (every hit becomes a frame),
+ * 8192 = no side mode (stage 2 of the primary phase in the launch stream, before the recursion levels, instead of beside them). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
@@ -336,7 +337,8 @@ typedef struct RtuTouched {
 int         rtu_get_touched(RtuContext* ctx, RtuTouched* per_slot, int n_slots);   /* synchronises; returns the slots written */
 /* A sampled frame (recipes S / P) is many launch sequences — one per batch of samples, ten per batch for recipe P — and its counters are
  * the sums over all of them: per_slot[i] = the number of launches of slot i's kernel that went into the table since it was zeroed
- * (bytes per launch = rtu_touched_bytes / launches). Slot 33 is recipe P's k_gi_roots. */
+ * (bytes per launch = rtu_touched_bytes / launches). Slot 33 is recipe P's k_gi_roots, slot 34 the k_tail launch of side mode (the few
+ * frames stage 2 of the primary phase makes, evaluated on the helper stream beside the recursion levels). */
 int         rtu_get_touched_launches(RtuContext* ctx, uint32_t* per_slot, int n_slots);
 unsigned long long rtu_touched_bytes(const RtuTouched* t, int textured);
 const char* rtu_kernel_slot_name(int slot);

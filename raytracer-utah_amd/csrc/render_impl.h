@@ -113,7 +113,8 @@ struct Stamp {
 };
 enum { RTU_TL_PRIMARY = 0, RTU_TL_PRIMARY2C = 1, RTU_TL_PRIMARY2 = 2, RTU_TL_LEVEL0 = 3 /* +4L: trace, trace2c, trace2, consume */,
        RTU_TL_COMBINE0 = 3 + 4 * RTU_MAX_LEVELS, RTU_TL_GI_ROOTS = RTU_TL_COMBINE0 + RTU_MAX_LEVELS /* recipe P: k_gi_roots */ };
-static_assert(RTU_TL_GI_ROOTS < RTU_TL_KERNELS, "timeline slots");
+#define RTU_TL_SIDE_TAIL (RTU_TL_GI_ROOTS + 1)  // side mode: the k_tail launch behind stage 2 of the primary phase
+static_assert(RTU_TL_SIDE_TAIL < RTU_TL_KERNELS, "timeline slots");
 
 // Wave-aggregated append: every lane with `want` gets a unique index into the level's
 // frame arrays; one atomic per wavefront. Must be reached by all 64 lanes.
@@ -245,7 +246,7 @@ __device__ __forceinline__ f3 secondary_dir(int slot, uint32_t info, f3 dir, f3 
 // call; `want` says whether the lane has a frame. Returns the frame index or ~0u.
 template <int TEX>
 __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, uint32_t shard, uint32_t info, f3 p, f3 N, uint32_t fbw, f3 dir,
-                                                float fcw, f3 uvw, Counters& cnt) {
+                                                float fcw, f3 uvw, Counters& cnt, const bool stage2 = false) {
     const LevelBuffers& lv = a.lv[0];
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
     const bool wm = want && (info & RTU_FI_MAIN), wc = want && (info & RTU_FI_C);
@@ -254,6 +255,7 @@ __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, 
     if (mf) {
         const uint32_t leader = (uint32_t)__ffsll((long long)mf) - 1u;
         if ((threadIdx.x & 63u) == leader) {
+            if (stage2) atomicAdd(&a.fcnt->stage2_frames[(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mf));  // (what the host decides side mode by: FrameCounters)
             bf = atomicAdd(&a.fcnt->n_frames[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mf));
             if (mm) bm = atomicAdd(&a.fcnt->n_lmain[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mm));
             if (mc) bc = atomicAdd(&a.fcnt->n_lrefl[0][(shard) * RTU_CSTRIDE], (uint32_t)__popcll(mc));
@@ -272,8 +274,12 @@ __device__ __forceinline__ uint32_t append_root(const KernelArgs& a, bool want, 
             lv.fa[idx] = make_float4(p.x, p.y, p.z, __uint_as_float(info));
             lv.fb[idx] = make_float4(N.x, N.y, N.z, __uint_as_float(fbw));
             lv.fc[idx] = make_float4(dir.x, dir.y, dir.z, fcw);
-            if (wm) lv.lmain[(size_t)shard * lv.cap_s + bm + (uint32_t)__popcll(mm & below)] = fl;
-            if (wc) lv.lrefl[(size_t)shard * lv.cap_s + bc + (uint32_t)__popcll(mc & below)] = fl;
+            // (the list counters also count the lanes of wavefronts that found the shard full — possible in the small side arrays of side mode —:
+            // an entry is written only inside the shard's region; the overflow is reported and the frame rendered again)
+            const uint32_t im = bm + (uint32_t)__popcll(mm & below), ic = bc + (uint32_t)__popcll(mc & below);
+            if (wm && im < lv.cap_s) lv.lmain[(size_t)shard * lv.cap_s + im] = fl;
+            if (wc && ic < lv.cap_s) lv.lrefl[(size_t)shard * lv.cap_s + ic] = fl;
+            if ((wm && im >= lv.cap_s) || (wc && ic >= lv.cap_s)) a.fcnt->overflow = 1;
         } else {
             a.fcnt->overflow = 1;
         }
@@ -333,6 +339,14 @@ __device__ __forceinline__ Smp frame_smp(const KernelArgs& a, int L, float fbw) 
 
 // Append one ray id to the defer list of phase `ph` (sharded like the frame arrays).
 __device__ __forceinline__ void defer_push(const KernelArgs& a, int ph, uint32_t shard, bool want, uint32_t id) {
+    if (ph == 0) {  // the primary phase has a list and counters of its own (KernelArgs::fcnt0)
+        uint32_t idx = wave_append(&a.fcnt0->n_defer[0][(shard) * RTU_CSTRIDE], want);
+        if (want) {
+            if (idx < a.defer_cap0_s) a.defer_list0[(size_t)shard * a.defer_cap0_s + idx] = id;
+            else a.fcnt0->overflow = 1;
+        }
+        return;
+    }
     uint32_t idx = wave_append(&a.fcnt->n_defer[ph][(shard) * RTU_CSTRIDE], want);
     if (want) {
         if (idx < a.defer_cap_s) a.defer_list[(size_t)shard * a.defer_cap_s + idx] = id;
@@ -346,8 +360,9 @@ struct NarrowGeom {
     uint32_t counts;  // lane i: the population of shard i (count_of)
 };
 __device__ __forceinline__ NarrowGeom narrow_geom(const KernelArgs& a, int ph) {
-    uint32_t v = a.fcnt->n_defer[ph][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
-    if (v > a.defer_cap_s) v = a.defer_cap_s;
+    uint32_t v = (ph == 0 ? a.fcnt0 : a.fcnt)->n_defer[ph][(lane_id() % RTU_SHARDS) * RTU_CSTRIDE];
+    const uint32_t capd = ph == 0 ? a.defer_cap0_s : a.defer_cap_s;
+    if (v > capd) v = capd;
     const uint32_t mine = v;
     uint32_t sum = v;
 #pragma unroll
@@ -526,7 +541,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
             want = false;
         }
     }
-    if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt);
+    if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt, !DEFER && !STATS);
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup
@@ -615,7 +630,7 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
         const uint32_t e = k * 64u + lane;
         const bool valid = e < ns;
         uint32_t pix = 0;
-        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        if (valid) pix = a.defer_list0[(size_t)shard * a.defer_cap0_s + e];
         if (valid) RTU_BYTES(4u);
         int x, y;
         uint32_t sidx;
@@ -652,7 +667,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
         const uint32_t e = k * groups + grp;
         const bool valid = e < ns;
         uint32_t pix = 0;
-        if (valid) pix = a.defer_list[(size_t)shard * a.defer_cap_s + e];
+        if (valid) pix = a.defer_list0[(size_t)shard * a.defer_cap0_s + e];
         if (valid && leader) RTU_BYTES(4u);
         int x, y;
         uint32_t sidx;
@@ -1298,8 +1313,8 @@ __global__ void __launch_bounds__(64) k_combine(KernelArgs a, int L) {
 // the host's choice); the regular k_combine of levels < Ls follow.
 #define RTU_TAIL_CAP 256  // frames of one level in one subtree: at most 3^4 = 81 for a cut at level 1, 243 in theory
 template <int TEX>
-__global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
-    const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * Ls);
+__global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls, int slot) {
+    const Stamp stamp(a, slot);
     __shared__ uint32_t s_stack[8 * RTU_STACK8];
     __shared__ uint32_t s_cur[RTU_MAX_LEVELS][RTU_TAIL_CAP];  // my frames of each level
     __shared__ uint32_t s_n[RTU_MAX_LEVELS];
@@ -1379,7 +1394,7 @@ __global__ void __launch_bounds__(64) k_tail(KernelArgs a, int Ls) {
         }
         __threadfence();
     }
-    flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * Ls);
+    flush_touched<TEX>(a, cnt, slot);
 }
 
 // ---- recipe P: MonteCarlo() of RenderFunctions.cpp:549-590 unrolled over the chain ---------------------
@@ -1753,14 +1768,15 @@ __global__ void __launch_bounds__(64) k_tile_occ(KernelArgs a, uint32_t entries)
 
 // One kernel of the sequence; `slot` is its timeline / counter-table slot. With a probe on that slot the launch is
 // bracketed by HIP events on the launch stream (bench.py: the dominant kernel's duration inside the timed region).
-#define RTU_LAUNCH(kslot_, kernel, grid, blk, ...)                                            \
+#define RTU_LAUNCH_ON(strm_, kslot_, kernel, grid, blk, ...)                                  \
     do {                                                                                     \
         const bool probed_ = probe && probe->slot == (kslot_);                               \
         if (a.host_launches) a.host_launches[(kslot_)]++;                                    \
-        if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev0, stream);                   \
-        hipLaunchKernelGGL(kernel, grid, blk, 0, stream, __VA_ARGS__);                       \
-        if (probed_) { (void)hipEventRecord((hipEvent_t)probe->ev1, stream); if (probe->recorded) *probe->recorded = 1; } \
+        if (probed_) (void)hipEventRecord((hipEvent_t)probe->ev0, (strm_));                  \
+        hipLaunchKernelGGL(kernel, grid, blk, 0, (strm_), __VA_ARGS__);                      \
+        if (probed_) { (void)hipEventRecord((hipEvent_t)probe->ev1, (strm_)); if (probe->recorded) *probe->recorded = 1; } \
     } while (0)
+#define RTU_LAUNCH(kslot_, kernel, grid, blk, ...) RTU_LAUNCH_ON(stream, kslot_, kernel, grid, blk, __VA_ARGS__)
 
 template <int STACK, int TEX>
 int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t stream, int mode = RTU_LAUNCH_ALL, const LaunchProbe* probe = nullptr) {
@@ -1808,7 +1824,23 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         if (!SMPD && !GID && a.occ) hipLaunchKernelGGL(k_tile_occ, dim3(a.occ_words / 2u, (BATD ? a.batch : 1u)), dim3(64), 0, stream, a, (BATD ? a.batch : 1u));
         if constexpr (SMPD || GID) RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary_sampled<STACK, TEX>), gridPF, dim3(256), a, n_tiles);
         else RTU_LAUNCH(RTU_TL_PRIMARY, (k_primary<STACK, false, TEX>), gridPF, dim3(256), a, n_tiles);
-        if (a.n_meshes) {  // without meshes nothing is ever deferred
+        if (a.n_meshes && a.side && mode == RTU_LAUNCH_ALL) {
+            // SIDE MODE (KernelArgs::fcnt0): stage 2 of the primary phase on the helper stream, beside the recursion levels. Its kernels
+            // get the side set of level arrays and counters; the few frames they make are evaluated by one k_tail launch behind them.
+            KernelArgs a2 = a;
+            for (int L = 0; L < RTU_MAX_LEVELS; L++) a2.lv[L] = a.lv_side[L];
+            a2.fcnt = a.fcnt0;
+            const hipStream_t aux = (hipStream_t)a.aux_stream;
+            (void)hipEventRecord((hipEvent_t)a.aux_ev0, stream);      // k_primary is queued: its defer list and counters are what stage 2 reads
+            (void)hipStreamWaitEvent(aux, (hipEvent_t)a.aux_ev0, 0);
+            {
+                const KernelArgs& a = a2;  // (the launch macro takes its arguments from `a`)
+                RTU_LAUNCH_ON(aux, RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
+                RTU_LAUNCH_ON(aux, RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);
+                RTU_LAUNCH_ON(aux, RTU_TL_SIDE_TAIL, (k_tail<TEX>), dim3(1024), block, a, 0, (int)RTU_TL_SIDE_TAIL);
+            }
+            (void)hipEventRecord((hipEvent_t)a.aux_ev1, aux);
+        } else if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
             RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);
         }
@@ -1834,8 +1866,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);
         }
     }
-    if (regular < levels) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * regular, (k_tail<TEX>), dim3(8192), block, a, regular);
+    if (regular < levels) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * regular, (k_tail<TEX>), dim3(8192), block, a, regular, RTU_TL_LEVEL0 + 4 * regular);
     for (int L = regular - 2 + (regular < levels ? 1 : 0); L >= 0; L--) RTU_LAUNCH(RTU_TL_COMBINE0 + L, (k_combine<TEX>), gridC, block, a, L);
+    if (!stats && a.n_meshes && a.side && mode == RTU_LAUNCH_ALL) (void)hipStreamWaitEvent(stream, (hipEvent_t)a.aux_ev1, 0);  // the frame is complete when stage 2's pixels are
     return (int)hipGetLastError();
 }
 

@@ -20,6 +20,8 @@
 struct RtuContext {
     int         device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;        // side mode (rtu_device.h KernelArgs::fcnt0): stage 2 of the primary phase runs here, beside the levels
+    hipEvent_t  aux_ev0 = nullptr, aux_ev1 = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     std::string error;
 
@@ -39,6 +41,14 @@ struct RtuContext {
     FrameCounters* fcnt = nullptr;
     uint32_t* defer_list = nullptr;
     uint32_t  defer_cap_s = 0;
+    FrameCounters* fcnt_side = nullptr;      // side mode: counters of the primary phase's defer list and of the side level arrays
+    uint32_t* defer_list0 = nullptr;         // the primary phase's own defer list
+    uint32_t  defer_cap0_s = 0;
+    LevelBuffers lv_side[RTU_MAX_LEVELS] = {};
+    std::map<uint64_t, bool> side_off;       // launch shapes whose stage 2 made more frames than the side arrays take: no side mode for them
+    std::map<uint64_t, uint64_t> side_frames; // ... and how many level-0 frames stage 2 of the primary phase made in the last launch of a shape
+    bool     last_side = false;
+    bool     mesh_hits_childless = false;    // no mesh node's material reflects or refracts: a mesh hit's Shade() call is settled by the lane that found it
     bool     any_recursive_material = true;
     bool     textured = false;
     bool     scene_stochastic = false;   // soft shadows / glossy bounces / depth of field: recipe S only
@@ -877,6 +887,9 @@ void free_levels(RtuContext* ctx) {
     for (void* p : ctx->level_allocs) (void)hipFree(p);
     ctx->level_allocs.clear();
     memset(ctx->lv, 0, sizeof ctx->lv);
+    memset(ctx->lv_side, 0, sizeof ctx->lv_side);
+    ctx->defer_list0 = nullptr;
+    ctx->defer_cap0_s = 0;
     ctx->level_cap0 = 0;
 }
 
@@ -910,7 +923,7 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     // defer list: at most every ray of the largest phase (all slots of the largest level)
     size_t dcap_s = maxcap * (ctx->nsl + 3);
     if (ctx->want_defer_s > dcap_s) dcap_s = ctx->want_defer_s;
-    if (fits && ctx->defer_cap_s >= dcap_s) return RTU_OK;
+    if (fits && ctx->defer_cap_s >= dcap_s && ctx->defer_list0 && ctx->defer_cap0_s >= cap_s0) return RTU_OK;
     free_levels(ctx);
     int rc;
     size_t total = 0;
@@ -940,6 +953,29 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     }
     if ((rc = alloc_level(ctx, &ctx->defer_list, dcap_s * RTU_SHARDS)) != RTU_OK) return rc;
     ctx->defer_cap_s = (uint32_t)dcap_s;
+    // the primary phase's own defer list (at most every pixel of the launch) and the side set of level arrays (rtu_device.h
+    // KernelArgs::fcnt0): small — a k_tail launch refuses more than RTU_TAIL_DECLINE frames anyway
+    if ((rc = alloc_level(ctx, &ctx->defer_list0, cap_s0 * RTU_SHARDS)) != RTU_OK) return rc;
+    ctx->defer_cap0_s = (uint32_t)cap_s0;
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        LevelBuffers& lv = ctx->lv_side[L];
+        const size_t cap_s = 256, cap = cap_s * RTU_SHARDS;
+        if ((rc = alloc_level(ctx, &lv.fa, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fb, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fc, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fres, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fchild, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fsh, cap * (ctx->nsl ? ctx->nsl : 1))) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fslot, cap * 6)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.fpend, cap)) != RTU_OK) return rc;
+        if (ctx->textured) {
+            if ((rc = alloc_level(ctx, &lv.fuv, cap)) != RTU_OK) return rc;
+            if ((rc = alloc_level(ctx, &lv.fsuv, cap * 3)) != RTU_OK) return rc;
+        }
+        if ((rc = alloc_level(ctx, &lv.lmain, cap)) != RTU_OK) return rc;
+        if ((rc = alloc_level(ctx, &lv.lrefl, cap)) != RTU_OK) return rc;
+        lv.cap_s = (uint32_t)cap_s;
+    }
     ctx->level_cap0 = pixels;
     ctx->level_nsl = ctx->nsl;
     return RTU_OK;
@@ -1001,6 +1037,9 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     a.tl = ctx->stamp_next ? ctx->tl : nullptr;
     a.defer_list = ctx->defer_list;
     a.defer_cap_s = ctx->defer_cap_s;
+    a.defer_list0 = ctx->defer_list0;
+    a.defer_cap0_s = ctx->defer_cap0_s;
+    a.fcnt0 = ctx->fcnt;
     a.dbg = ctx->dbg;
     a.scene.dbg = ctx->dbg;
     a.counters = stats ? ctx->counters : nullptr;
@@ -1095,6 +1134,36 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         a.gi_depth = (uint32_t)gi_depth;
         a.gi_total = pixels * (uint32_t)batch;
     }
+    // side mode (rtu_device.h KernelArgs::fcnt0): recipe W's fast variant on a scene with meshes, unless this launch shape has shown that
+    // its stage 2 makes more frames than a k_tail launch takes (rtu_debug_flags 8192: never — results must not change)
+    // Only where it pays and cannot surprise: every mesh node's material is childless (stage 2's frames are then the rare hits whose
+    // shadow rays could not be settled inline — a mirror teapot would send every hit through the k_tail launch), and the last launch of
+    // this shape deferred enough primary rays for the one-lane-per-ray stage 2 (a first launch, or a short list: the old order).
+    ctx->last_side = false;
+    const uint32_t thr0 = (uint32_t)(frame->coop_threshold > 0 ? frame->coop_threshold : 70000);
+    if (stats != 1 && !gi && frame->samples == 0 && ctx->n_meshes > 0 && ctx->mesh_hits_childless && !ctx->stamp_next && !(ctx->dbg & (8192u | 2048u | 64u)) &&
+        ctx->dscene.node_bounds && ctx->dscene.lmask &&  // (the occluder lists are what settles a mesh hit's shadow rays inline)
+        !ctx->side_off.count(tail_key) && ctx->list_hints.count(tail_key) && ctx->list_hints[tail_key][0] - 1u > thr0 &&
+        ctx->side_frames.count(tail_key) && ctx->side_frames[tail_key] <= 256u) {
+        if (!ctx->aux_stream) {
+            // created at first use: the helper stream of side mode, lowest priority. (A context that never uses side mode creates no stream
+            // for it: HIP deals its hardware queues out in creation order — four by default, GPU_MAX_HW_QUEUES —, and a stream too many makes
+            // two streams that are meant to overlap share a queue: two contexts alternating, 56.8 -> 47.5 Grays/s, measured.)
+            int prio_least = 0, prio_greatest = 0;
+            RTU_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            RTU_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_least));
+            RTU_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev0, hipEventDisableTiming));
+            RTU_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev1, hipEventDisableTiming));
+        }
+        a.side = 1;
+        a.fcnt0 = ctx->fcnt_side;
+        memcpy(a.lv_side, ctx->lv_side, sizeof a.lv_side);
+        a.aux_stream = ctx->aux_stream;
+        a.aux_ev0 = ctx->aux_ev0;
+        a.aux_ev1 = ctx->aux_ev1;
+        RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt_side, 0, offsetof(FrameCounters, overflow), stream));  // (ahead of k_primary, which fills its defer counters)
+        ctx->last_side = true;
+    }
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
@@ -1123,7 +1192,13 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
 
 // After the stream has drained: did any recursion level run out of frame capacity?
 // Frames per level of the frame just finished -> where k_tail may take over in the next one.
-void learn_tail(RtuContext* ctx, const FrameCounters& h) {
+uint64_t stage2_total(const FrameCounters& h) {
+    uint64_t n = 0;
+    for (int s = 0; s < RTU_SHARDS; s++) n += h.stage2_frames[s * RTU_CSTRIDE];
+    return n;
+}
+
+void learn_tail(RtuContext* ctx, const FrameCounters& h, const FrameCounters* side) {
     static const uint32_t kTailEnv = [] { const char* e = getenv("RTU_TAIL_LEARN"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0u; }();  // tuning knob
     const uint32_t kTailMax = kTailEnv ? kTailEnv : RTU_TAIL_LEARN;  // frames of the cut level, one wavefront each: measured, a few thousand subtrees evaluated
                                                // wavefront by wavefront are slower than their levels kernel by kernel
@@ -1143,7 +1218,8 @@ void learn_tail(RtuContext* ctx, const FrameCounters& h) {
     std::array<uint32_t, 8> lh{};
     for (int p = 0; p <= RTU_MAX_LEVELS && p < 8; p++) {
         uint64_t n = 0;
-        for (int s = 0; s < RTU_SHARDS; s++) n += h.n_defer[p][(s) * RTU_CSTRIDE];
+        const FrameCounters& from = (p == 0 && side) ? *side : h;  // (side mode: the primary phase counts in the side counters)
+        for (int s = 0; s < RTU_SHARDS; s++) n += from.n_defer[p][(s) * RTU_CSTRIDE];
         lh[p] = (uint32_t)(n < 0xFFFFFFF0ull ? n : 0xFFFFFFF0ull) + 1u;
     }
     ctx->list_hints[ctx->last_tail_key] = lh;
@@ -1156,9 +1232,35 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
     std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
     FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
-    *overflow = h.overflow != 0 || h.tail_declined != 0;
+    // side mode: stage 2 of the primary phase made more frames than its k_tail launch takes (or than the side arrays hold): the
+    // frames of this report are incomplete, and this launch shape goes without side mode from now on
+    std::unique_ptr<FrameCounters> sp;
+    bool side_failed = false;
+    {
+        uint32_t flags[2] = {0, 0};
+        RTU_HIP(ctx, hipMemcpy(flags, &ctx->fcnt_side->overflow, sizeof flags, hipMemcpyDeviceToHost));
+        if (flags[0] || flags[1]) {
+            side_failed = true;
+            ctx->side_off[ctx->last_tail_key] = true;
+            RTU_HIP(ctx, hipMemset(&ctx->fcnt_side->overflow, 0, 2 * sizeof(uint32_t)));
+        }
+        if (ctx->last_side) {
+            sp.reset(new FrameCounters);
+            RTU_HIP(ctx, hipMemcpy(sp.get(), ctx->fcnt_side, sizeof(FrameCounters), hipMemcpyDeviceToHost));
+            ctx->side_frames[ctx->last_tail_key] = stage2_total(*sp);
+            if (getenv("RTU_SIDE_VERBOSE")) {
+                unsigned long long f[RTU_MAX_LEVELS] = {}, d0 = 0;
+                for (int L = 0; L < RTU_MAX_LEVELS; L++)
+                    for (int s = 0; s < RTU_SHARDS; s++) f[L] += sp->n_frames[L][s * RTU_CSTRIDE];
+                for (int s = 0; s < RTU_SHARDS; s++) d0 += sp->n_defer[0][s * RTU_CSTRIDE];
+                fprintf(stderr, "[side] deferred pixels %llu, side frames per level %llu %llu %llu %llu %llu %llu, failed %d\n", d0, f[0], f[1], f[2], f[3], f[4], f[5], (int)side_failed);
+            }
+        }
+    }
+    if (!ctx->last_side && !ctx->last_stats) ctx->side_frames[ctx->last_tail_key] = stage2_total(h);  // (the fast variant without side mode: counted in the main counters)
+    *overflow = h.overflow != 0 || h.tail_declined != 0 || side_failed;
     if (!*overflow) {
-        learn_tail(ctx, h);
+        learn_tail(ctx, h, sp.get());
         return RTU_OK;
     }
     RTU_HIP(ctx, hipMemset(&ctx->fcnt->overflow, 0, 2 * sizeof(uint32_t)));  // reported: the next status starts clean (overflow, tail_declined)
@@ -1316,6 +1418,7 @@ RtuContext* rtu_create_context(int device_id, int* err_out) {
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&ctx->fcnt_side, sizeof(FrameCounters)) == hipSuccess && hipMemset(ctx->fcnt_side, 0, sizeof(FrameCounters)) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc((void**)&ctx->counters, kCounterBytes) == hipSuccess &&
               hipMalloc((void**)&ctx->fcnt, sizeof(FrameCounters)) == hipSuccess &&
@@ -1334,6 +1437,10 @@ void rtu_destroy_context(RtuContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->aux_ev0) (void)hipEventDestroy(ctx->aux_ev0);
+    if (ctx->aux_ev1) (void)hipEventDestroy(ctx->aux_ev1);
+    if (ctx->fcnt_side) (void)hipFree(ctx->fcnt_side);
     free_scene(ctx);
     free_levels(ctx);
     if (ctx->fcnt) (void)hipFree(ctx->fcnt);
@@ -1603,6 +1710,16 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     ctx->list_hints.clear();
     ctx->n_meshes = s->n_meshes;
     ctx->mesh_info = mesh_info;
+    ctx->mesh_hits_childless = true;
+    for (uint32_t i = 0; i < s->n_nodes; i++) {
+        const RtuNode& nd = s->nodes[i];
+        if (nd.obj_type != RTU_OBJ_TRIMESH || nd.material_id < 0) continue;
+        const RtuMaterial& mm = s->materials[nd.material_id];
+        for (int k = 0; k < 3; k++)
+            if (mm.reflection[k] != 0 || mm.refraction[k] != 0) ctx->mesh_hits_childless = false;
+    }
+    ctx->side_off.clear();
+    ctx->side_frames.clear();
     ctx->any_recursive_material = false;
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const RtuMaterial& mm = s->materials[i];
@@ -1754,7 +1871,7 @@ int rtu_get_stats(RtuContext* ctx, RtuStats* stats) {
     std::unique_ptr<FrameCounters> hp(new FrameCounters);  // a quarter of a megabyte: not on the stack
     FrameCounters& h = *hp;
     RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt, sizeof h, hipMemcpyDeviceToHost));
-    if (!h.overflow) learn_tail(ctx, h);
+    if (!h.overflow) learn_tail(ctx, h, nullptr);  // (after a counting render: no side mode)
     return RTU_OK;
 }
 
@@ -1794,6 +1911,7 @@ const char* rtu_kernel_slot_name(int slot) {
     if (slot < 3 + 4 * RTU_MAX_LEVELS) snprintf(buf[slot], sizeof buf[slot], "%s(L%d)", level_kernels[(slot - 3) % 4], (slot - 3) / 4);
     else if (slot < 3 + 5 * RTU_MAX_LEVELS) snprintf(buf[slot], sizeof buf[slot], "k_combine(L%d)", slot - (3 + 4 * RTU_MAX_LEVELS));
     else if (slot == 3 + 5 * RTU_MAX_LEVELS) return "k_gi_roots";
+    else if (slot == 4 + 5 * RTU_MAX_LEVELS) return "k_tail(side)";
     else return "";
     return buf[slot];
 }
@@ -2073,6 +2191,12 @@ int rtu_frame_counts(RtuContext* ctx, uint32_t* frames_out, uint32_t* deferred_o
     for (int p = 0; p <= RTU_MAX_LEVELS; p++) {
         deferred_out[p] = 0;
         for (int s = 0; s < RTU_SHARDS; s++) deferred_out[p] += h.n_defer[p][(s) * RTU_CSTRIDE];
+    }
+    if (ctx->last_side) {  // side mode: the primary phase's defer list and the frames its stage 2 made are counted apart (KernelArgs::fcnt0)
+        RTU_HIP(ctx, hipMemcpy(&h, ctx->fcnt_side, sizeof h, hipMemcpyDeviceToHost));
+        for (int L = 0; L < RTU_MAX_LEVELS; L++)
+            for (int s = 0; s < RTU_SHARDS; s++) frames_out[L] += h.n_frames[L][(s) * RTU_CSTRIDE];
+        for (int s = 0; s < RTU_SHARDS; s++) deferred_out[0] += h.n_defer[0][(s) * RTU_CSTRIDE];
     }
     return RTU_OK;
 }

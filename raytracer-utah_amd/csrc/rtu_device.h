@@ -260,6 +260,7 @@ struct FrameCounters {
     uint32_t n_pending[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];    // frames waiting for children (fpend)
     uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];      // entries of lmain / lrefl
     uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];
+    uint32_t stage2_frames[RTU_SHARDS * RTU_CSTRIDE];  // level-0 frames appended by stage 2 of the primary phase, per shard like the lists (what the host decides side mode by; zeroed per launch)
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more (sticky: rtu_frame_status)
     uint32_t tail_declined;  // k_tail found more frames at its cut level than it takes (RTU_TAIL_DECLINE): it evaluated nothing, the frame
                              // is incomplete and must be rendered again without the tail (sticky, reported like an overflow)
@@ -275,10 +276,29 @@ struct KernelArgs {
     RtuFrameDesc frame;
     float4*      out;               // shard rows * width
     LevelBuffers lv[RTU_MAX_LEVELS];
+    LevelBuffers lv_side[RTU_MAX_LEVELS];   // side mode: the level arrays of the frames stage 2 of the primary phase makes (HOST ONLY: copied into lv for its launches)
     unsigned long long* tl;         // GPU-clock timeline stamps (rtu_render_timeline) or nullptr
     FrameCounters* fcnt;
-    uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel
+    uint32_t*    defer_list;        // [RTU_SHARDS * defer_cap_s] ray ids waiting for the narrow stage-2 kernel (phases 1..: the levels' rays)
     uint32_t     defer_cap_s;
+    // THE PRIMARY PHASE'S OWN LIST AND COUNTERS. Stage 2 of the primary rays (k_primary2 / k_primary2c: a third of the launch sequence,
+    // instruction-bound) depends on k_primary alone, and the recursion levels (twenty small latency-bound kernels) depend on the frames
+    // k_primary made — not on stage 2's, which on most scenes are a handful (a mesh whose material neither reflects nor refracts is
+    // shaded by the lane that found the hit; what remains are hits whose shadow rays could not be settled without a walk). So stage 2
+    // runs on the context's helper stream BESIDE the levels ("side mode", chosen by the host per launch): its deferred pixels come from
+    // a list of their own (defer_list0, counted in fcnt0->n_defer[0]), the frames it does make go into a small separate set of level
+    // arrays and counters (the kernel arguments it is launched with: lv = side arrays, fcnt = fcnt0), and ONE k_tail launch behind it
+    // evaluates those frames, subtree by subtree. The host chooses side mode only for a launch shape whose stage 2 made at most a few
+    // hundred frames last time (FrameCounters::stage2_frames) — a mirror teapot, or a glass sphere seen through the mesh's bounding
+    // box, make thousands, and a k_tail launch is the wrong tool for those; should the view have changed since: more than the side
+    // arrays hold or than k_tail takes is refused on the device, reported like an overflow, and the shape goes without side mode.
+    // Without side mode fcnt0 == fcnt.
+    FrameCounters* fcnt0;
+    uint32_t*    defer_list0;       // [RTU_SHARDS * defer_cap0_s] pixels waiting for stage 2 of the primary phase
+    uint32_t     defer_cap0_s, side;  // side: 1 in side mode
+    void*        aux_stream;        // HOST ONLY (launch_all): the helper stream and two events of side mode
+    void*        aux_ev0;
+    void*        aux_ev1;
     uint32_t     dbg;               // experiment switches (rtu_debug_flags); 0 in production
     // COVERAGE MASKS of primary rays (recipe W): per camera of the launch and mesh node, one bit per 8x8-pixel tile of the image:
     // can a primary ray through a pixel of the tile touch ANY triangle of the mesh? (k_mesh_cover: every triangle's world box, widened by

@@ -1330,3 +1330,58 @@ def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
     finally:
         pkg.hip.rtu_debug_flags(ctx._h, 0)
         pkg.hip.rtu_device_free(ctx._h, d)
+
+
+def test_stage2_of_the_primary_phase_beside_the_recursion_levels(pkg, ctx, golden):
+    """Round 3, side mode (rtu_device.h KernelArgs::fcnt0): once a launch shape has shown that stage 2 of its primary phase is the
+    one-lane-per-ray kernel and makes at most a few hundred frames, that kernel runs on the context's helper stream beside the
+    recursion levels, with a defer list, counters and a small set of level arrays of its own and one k_tail launch behind it.
+    The images must be those of the launch-stream order (rtu_debug_flags 8192) and of the frames rendered alone, bit for bit;
+    the touched-bytes table shows that the mode was in fact taken (slot k_tail(side)) and its bookkeeping still adds up."""
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H, n = g.width, g.height, 4
+    cams = []
+    for i in range(n):
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        cam.pos[0] += 0.6 * i
+        cam.pos[2] += 0.2 * i
+        cams.append(cam)
+    singles = [ctx.render(pkg.frame_setup(c, W, H))[0] for c in cams]
+    assert sha256(singles[0][..., 3]) == g.meta["sha256_z_f32"]
+    d = pkg.hip.rtu_device_alloc(ctx._h, n * W * H * 16)
+    got = np.empty((n, H, W, 4), np.float32)
+
+    def render(stats):
+        fs = [pkg.frame_setup(c, W, H, collect_stats=stats) for c in cams]
+        for attempt in range(8):
+            ctx.render_frames_device(fs, d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as e:
+                if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                    raise
+        assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+        return got.copy()
+    try:
+        for flags in (8192, 0):
+            pkg.hip.rtu_debug_flags(ctx._h, flags)
+            for rep in range(3):  # the first launches of a shape teach the context its habits; the third is in side mode (flags 0)
+                out = render(0)
+                for i in range(n):
+                    assert np.array_equal(out[i].view(np.uint32), singles[i].view(np.uint32)), "flags %d, launch %d: frame %d differs" % (flags, rep, i)
+            out = render(2)
+            t = ctx.touched(False)
+            for i in range(n):
+                assert np.array_equal(out[i].view(np.uint32), singles[i].view(np.uint32)), "flags %d, touched-bytes mode: frame %d differs" % (flags, i)
+            assert ("k_tail(side)" in t or t.get("k_primary2", {}).get("rays", 0) > 0)
+            if flags == 0:
+                assert "k_primary2" in t and "k_primary2c" not in t  # the long list: one lane per ray
+                _, deferred = ctx.frame_counts()
+                walks = lambda k: t[k]["rays"] - t[k]["inline_shadow_rays"] if k in t else 0
+                assert walks("k_primary") == n * W * H and walks("k_primary2") == deferred[0] > 70000
+    finally:
+        pkg.hip.rtu_debug_flags(ctx._h, 0)
+        pkg.hip.rtu_device_free(ctx._h, d)

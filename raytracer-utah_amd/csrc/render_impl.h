@@ -614,12 +614,12 @@ __device__ __forceinline__ void stage_nodes(const KernelArgs& a, float4* lds_nod
 
 // stage 2 of the primary phase, long lists: one lane per deferred pixel, 64 per wavefront
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a) {
+__global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a, int alone) {
     const Stamp stamp(a, RTU_TL_PRIMARY2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, 0);
-    if (g.R == 8u) return;  // short list: k_primary2c takes it
+    if (g.R == 8u && !alone) return;  // short list: k_primary2c takes it (alone: it was not launched — launch_all)
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
@@ -821,12 +821,12 @@ __global__ void __launch_bounds__(64) k_trace_counting(KernelArgs a, int L, int 
 
 // stage 2, long lists: one lane per deferred ray
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L, int sel, int ph) {
+__global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L, int sel, int ph, int alone) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 2);
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     const NarrowGeom g = narrow_geom(a, ph);
-    if (g.R == 8u) return;  // short list: k_trace2c takes it
+    if (g.R == 8u && !alone) return;  // short list: k_trace2c takes it (alone: it was not launched — launch_all)
     const uint32_t kmax = (g.nmax + 63u) / 64u;
     const uint32_t chunks = kmax * RTU_SHARDS;
     Counters cnt = {};
@@ -1803,6 +1803,14 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
         return (n1 != 0u && n1 - 1u > 2u * (uint64_t)thr) ? dim3(16) : gridCoop;
     };
+    // SIDE MODE ONLY: the cooperative kernel of a phase whose list was beyond the threshold last time is not launched at all, and the
+    // one-lane-per-ray kernel takes the list whatever its length turns out to be (any choice renders the same image). Idle, that kernel
+    // costs nothing in an empty machine (launches overlap in the command processor: measured) — but its 1024-thread workgroups want a
+    // CU's whole LDS, and beside stage 2 of the primary phase no CU is ever empty: the idle launch waited 144 us for one (kernel trace).
+    auto no_coop = [&](int ph) {
+        const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
+        return a.side && n1 != 0u && n1 - 1u > (uint64_t)thr;
+    };
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
     const uint32_t blocksP = (n_tiles + 3) / 4;
@@ -1835,14 +1843,14 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             (void)hipStreamWaitEvent(aux, (hipEvent_t)a.aux_ev0, 0);
             {
                 const KernelArgs& a = a2;  // (the launch macro takes its arguments from `a`)
-                RTU_LAUNCH_ON(aux, RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
-                RTU_LAUNCH_ON(aux, RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);
+                // (side mode is only chosen when the last launch's list was the one-lane-per-ray kernel's: no cooperative launch)
+                RTU_LAUNCH_ON(aux, RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, 1);
                 RTU_LAUNCH_ON(aux, RTU_TL_SIDE_TAIL, (k_tail<TEX>), dim3(1024), block, a, 0, (int)RTU_TL_SIDE_TAIL);
             }
             (void)hipEventRecord((hipEvent_t)a.aux_ev1, aux);
         } else if (a.n_meshes) {  // without meshes nothing is ever deferred
             RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
-            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, 0);
         }
     }
     if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
@@ -1860,8 +1868,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L, (k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, a, L, sel, ph);
             if (a.n_meshes) {
-                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop(ph), dim3(RTU_COOP_THREADS), a, L, sel, ph);
-                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph);
+                const bool nc = no_coop(ph);
+                if (!nc) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop(ph), dim3(RTU_COOP_THREADS), a, L, sel, ph);
+                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph, nc ? 1 : 0);
             }
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);
         }

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf gpurun_out/trace_seq; mkdir -p gpurun_out/trace_seq
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_seq -- python3 bench.py --no-cpu --contexts 1 --steps ${STEPS:-64} --warmup 32 --repeats 2 > gpurun_out/trace_seq/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_seq -- python3 bench.py --no-cpu --contexts 1 --steps ${STEPS:-64} --warmup 32 --repeats 2 $BENCH_ARGS > gpurun_out/trace_seq/log.txt 2>&1
 python3 - <<PY
 import csv, glob
 f = sorted(glob.glob("gpurun_out/trace_seq/*/*_kernel_trace.csv"))[-1]

@@ -1803,13 +1803,15 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
         return (n1 != 0u && n1 - 1u > 2u * (uint64_t)thr) ? dim3(16) : gridCoop;
     };
-    // SIDE MODE ONLY: the cooperative kernel of a phase whose list was beyond the threshold last time is not launched at all, and the
-    // one-lane-per-ray kernel takes the list whatever its length turns out to be (any choice renders the same image). Idle, that kernel
-    // costs nothing in an empty machine (launches overlap in the command processor: measured) — but its 1024-thread workgroups want a
-    // CU's whole LDS, and beside stage 2 of the primary phase no CU is ever empty: the idle launch waited 144 us for one (kernel trace).
+    // The cooperative kernel of a phase whose list was beyond the threshold last time is not launched at all, and the one-lane-per-ray
+    // kernel takes the list whatever its length turns out to be (`alone`; any choice renders the same image). Idle, that kernel costs
+    // nothing in an EMPTY machine (launches overlap in the command processor: measured) — but its 1024-thread workgroups want a CU's
+    // whole LDS and sixteen wavefront slots, and beside another stream's kernels (side mode's stage 2 of the primary phase, another
+    // context's sequence) no CU is ever empty: kernel traces show the idle launch waiting 144 - 1500 us for one, the launch sequence
+    // stalled behind it. (rtu_debug_flags 16384: launch both outside side mode, as before.)
     auto no_coop = [&](int ph) {
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
-        return a.side && n1 != 0u && n1 - 1u > (uint64_t)thr;
+        return (a.side || !(a.dbg & 16384u)) && n1 != 0u && n1 - 1u > (uint64_t)thr;
     };
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
@@ -1849,8 +1851,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             }
             (void)hipEventRecord((hipEvent_t)a.aux_ev1, aux);
         } else if (a.n_meshes) {  // without meshes nothing is ever deferred
-            RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
-            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, 0);
+            const bool nc = no_coop(0);
+            if (!nc) RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
+            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, nc ? 1 : 0);
         }
     }
     if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();

@@ -1332,6 +1332,64 @@ def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
         pkg.hip.rtu_device_free(ctx._h, d)
 
 
+def test_idle_cooperative_launches_dropped_and_a_wrong_hint_is_harmless(pkg, ctx, golden):
+    """Round 3: a phase whose list was the one-lane-per-ray kernel's last time launches no (idle) cooperative kernel — its workgroups
+    want a whole CU and stall the sequence beside another stream's kernels — and the one-lane-per-ray kernel takes the list WHATEVER
+    its length turns out to be. So a batch of the same shape whose lists are short this time (the cameras moved away) is rendered
+    by the kernel the hint chose, not the one the threshold would: the images must still be the single frames', bit for bit; and
+    rtu_debug_flags 16384 (both kernels launched, as before) renders the same."""
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H, n = g.width, g.height, 4
+
+    def cams_at(scale):
+        out = []
+        for i in range(n):
+            cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+            for k in range(3):
+                cam.pos[k] *= scale
+            cam.pos[0] += 0.5 * i
+            out.append(cam)
+        return out
+    near, far = cams_at(1.0), cams_at(3.5)
+    singles = {id(c): ctx.render(pkg.frame_setup(c, W, H))[0] for c in near + far}
+    d = pkg.hip.rtu_device_alloc(ctx._h, n * W * H * 16)
+    got = np.empty((n, H, W, 4), np.float32)
+
+    def render(cams, stats=0):
+        fs = [pkg.frame_setup(c, W, H, collect_stats=stats) for c in cams]
+        for attempt in range(8):
+            ctx.render_frames_device(fs, d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as e:
+                if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                    raise
+        assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+        for i, c in enumerate(cams):
+            assert np.array_equal(got[i].view(np.uint32), singles[id(c)].view(np.uint32)), "frame %d differs" % i
+    try:
+        for flags in (8192, 8192 | 16384, 0):
+            pkg.hip.rtu_debug_flags(ctx._h, flags)
+            render(near)
+            render(near)              # the shape's hint: long lists
+            _, deferred = ctx.frame_counts()
+            assert deferred[0] > 70000
+            render(far)               # same shape, short lists: rendered by the kernels the hint chose
+            _, deferred = ctx.frame_counts()
+            assert 0 < deferred[0] < 70000
+            render(far)               # ... and by the ones the new hint chooses
+            render(near)              # and back: the cooperative kernel's grid meets a long list
+            render(near, 2)
+            t = ctx.touched(False)
+            assert "k_primary2" in t and "k_primary2c" not in t
+    finally:
+        pkg.hip.rtu_debug_flags(ctx._h, 0)
+        pkg.hip.rtu_device_free(ctx._h, d)
+
+
 def test_stage2_of_the_primary_phase_beside_the_recursion_levels(pkg, ctx, golden):
     """Round 3, side mode (rtu_device.h KernelArgs::fcnt0): once a launch shape has shown that stage 2 of its primary phase is the
     one-lane-per-ray kernel and makes at most a few hundred frames, that kernel runs on the context's helper stream beside the

@@ -1,12 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/cfg5q
-for v in "$@"; do
-  env $v python bench.py --tag p11_1080 --samples 64 --paths --steps 2 --warmup 1 --repeats 2 --no-cpu --rays-per-frame 661228579 > gpurun_out/cfg5q/out.json 2>/dev/null
-  python - <<PY
+python bench.py --tag p11_1080 --samples 16 --paths --steps 1 --warmup 1 --repeats 3 --no-cpu --rays-per-frame 1000000 > gpurun_out/c5.json 2> gpurun_out/c5.err || { tail -3 gpurun_out/c5.err; exit 1; }
+python - <<PY
 import json
-d = json.loads(open("gpurun_out/cfg5q/out.json").read().strip().splitlines()[-1])
-ks = d["roofline"]["kernels"]
-print("$v", d["ms_per_step"], " ".join("%s=%.0fx%d" % (k, 1000 * v["ms"], v["launches_per_frame"]) for k, v in list(ks.items())[:5]))
+d = json.loads(open("gpurun_out/c5.json").read().strip().splitlines()[-1])
+print("cfg5 16 spp ms/frame", d["ms_per_step"])
+ks = d["roofline"].get("kernels", {})
+print("   ", " ".join("%s=%.0f" % (k, 1000 * v.get("ms", 0)) for k, v in ks.items() if v.get("ms", 0) > 0.004))
 PY
-done

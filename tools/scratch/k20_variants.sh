@@ -13,3 +13,7 @@ run --frames-in-flight 10 --contexts 2
 run --frames-in-flight 10 --contexts 2 --dbg 8192
 run --frames-in-flight 10 --contexts 1
 run --frames-in-flight 7 --contexts 3
+run --frames-in-flight 10 --contexts 2 --coop-threshold 1
+run --frames-in-flight 10 --contexts 2 --coop-threshold 20000
+run --coop-threshold 1
+run --coop-threshold 20000

@@ -1248,7 +1248,8 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
             sp.reset(new FrameCounters);
             RTU_HIP(ctx, hipMemcpy(sp.get(), ctx->fcnt_side, sizeof(FrameCounters), hipMemcpyDeviceToHost));
             ctx->side_frames[ctx->last_tail_key] = stage2_total(*sp);
-            if (getenv("RTU_SIDE_VERBOSE")) {
+            static const bool kSideVerbose = getenv("RTU_SIDE_VERBOSE") != nullptr;  // diagnostics: what side mode's stage 2 made, per status check
+            if (kSideVerbose) {
                 unsigned long long f[RTU_MAX_LEVELS] = {}, d0 = 0;
                 for (int L = 0; L < RTU_MAX_LEVELS; L++)
                     for (int s = 0; s < RTU_SHARDS; s++) f[L] += sp->n_frames[L][s * RTU_CSTRIDE];

@@ -9,7 +9,8 @@ TAG=${TAG:-r03}
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 # (--repeats 2: the profiler serialises and pads every launch; two regions of 64 frames are 4 launch sequences of 32 after the warm-up)
-B="python3 bench.py --steps 64 --warmup 32 --repeats 2 --no-cpu $BENCH_ARGS"
+# (--contexts 1: one launch sequence at a time, so that tools/profile_summary.py can tell the levels of the kernels by their order)
+B="python3 bench.py --steps 64 --warmup 32 --repeats 2 --no-cpu --contexts 1 $BENCH_ARGS"
 echo "$B" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1 || exit 1

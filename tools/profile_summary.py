@@ -47,9 +47,13 @@ def slot_names(rows):
             seq[k] += 1
         elif k == "k_tail":
             out[did] = "k_tail"
-        else:
-            out[did] = "%s(L%d)" % (k, seq[k])
+        elif k == "k_trace":
+            out[did] = "k_trace(L%d)" % seq[k]
             seq[k] += 1
+        else:
+            # the stage-2 kernels and k_consume of a level follow its k_trace (an idle stage-2 launch may have been dropped: the level is
+            # the last k_trace's, not the count of this kernel's own launches)
+            out[did] = "%s(L%d)" % (k, max(seq["k_trace"] - 1, 0))
     # k_combine runs bottom-up: the LAST one of a sequence is level 0
     ids = sorted(out)
     i = 0

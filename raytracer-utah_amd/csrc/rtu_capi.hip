@@ -609,7 +609,8 @@ bool compute_light_list(const RtuLight& l, const CoverMesh& cm, float wscale, Ho
             if (!std::isfinite(mag) || (U1 - U0) < 1e-4 * mag || (V1 - V0) < 1e-4 * mag) return false;  // no extent a float lookup could resolve
             // grid size: a triangle of an evenly tessellated surface spans ~ G / sqrt(nf / 2) cells; aim at six of them
             uint32_t G = 64;
-            while (G < RTU_LGRID_MAX && (double)G < 6.0 * std::sqrt((double)nf * 0.5)) G *= 2;
+            static const double kSpan = [] { const char* e = getenv("RTU_LGRID_SPAN"); return e ? atof(e) : 6.0; }();  // tuning knob (any value renders the same image)
+            while (G < RTU_LGRID_MAX && (double)G < kSpan * std::sqrt((double)nf * 0.5)) G *= 2;
             for (;; G /= 2) {
                 if (G < 16u) { ok = false; break; }
                 // the grid spans the extent plus two cells on every side

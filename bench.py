@@ -122,8 +122,8 @@ def main():
     ap.add_argument("--rays-per-frame", type=int, default=0,
                     help="diagnostic only: skip the (slow, untimed) counting pass that counts the reference's rays per frame and use this number instead — "
                          "for profiler runs of sampled frames, where the counting variant would drown the timed kernels in the trace")
-    ap.add_argument("--contexts", type=int, default=2,
-                    help="N=1: launch sequences alternate over this many contexts, each on a stream of its own (default 2): the latency-bound recursion "
+    ap.add_argument("--contexts", type=int, default=3,
+                    help="N=1: launch sequences alternate over this many contexts, each on a stream of its own (default 3; measured 1 / 2 / 3 / 4: 47.7 / 55.4 / 57.5 / 55.0 Grays/s): the latency-bound recursion "
                          "levels of one sequence overlap the primary kernels of the next. Only when the timed region holds at least that many full "
                          "batches (the driver's --steps 20 is one batch: one context)")
     ap.add_argument("--same-camera", action="store_true", help="diagnostic only: every frame of a batch from the golden camera (no turntable)")
@@ -229,7 +229,7 @@ def main():
             gathers = [torch.empty(world, B * max_rows * W * 4, dtype=torch.float32, device=cdev) for _ in range(2)]
     shard = shards[0]
     stream = torch.cuda.current_stream().cuda_stream
-    # N = 1: C contexts, each with its own stream and image buffer; batch i goes to context i mod C. Two launch sequences in flight:
+    # N = 1: C contexts, each with its own stream and image buffer; batch i goes to context i mod C. C launch sequences in flight:
     # the deep recursion levels of one (small, latency-bound kernels) overlap the primary kernels of the other (instruction-bound)
     C = 1
     if world == 1 and not sampled and args.contexts > 1 and args.steps >= args.contexts * B and B > 1:
@@ -518,7 +518,7 @@ def main():
                        "cameras": "one per frame of a batch: the scene's camera orbited by %g degrees per frame (frame 0 = the golden camera)" % ORBIT_STEP_DEG
                                   if len(set(rays_of)) > 1 or not (args.same_camera or sampled) else "the scene's camera for every frame",
                        "batch_latency_ms": round(kernel_ms, 4),  # HIP-event time of ONE launch sequence of frames_in_flight frames
-                       "launch_sequences_in_flight": C,  # contexts / streams the batches alternate over (two: the deep levels of one sequence overlap the primary kernels of the next)
+                       "launch_sequences_in_flight": C,  # contexts / streams the batches alternate over (the deep levels of one sequence overlap the primary kernels of the others)
                        "repeats": {"n": R, "region_ms_median": round(elapsed * 1e3, 4), "region_ms_min": round(min(region_s) * 1e3, 4),
                                    "region_ms_max": round(max(region_s) * 1e3, 4), "region_ms_first": round(region_s[0] * 1e3, 4),
                                    "timed_ms_total": round(sum(region_s) * 1e3, 2),

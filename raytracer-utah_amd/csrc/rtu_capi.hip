@@ -904,9 +904,10 @@ int alloc_level(RtuContext* ctx, T** dst, size_t count) {
 }
 
 // Frame arrays of every recursion level (rtu_device.h). Level 0 holds at most one frame per
-// pixel; a deeper level starts with the same capacity and is grown to what an overflowed frame
-// reported (check_overflow) — a frame can hold up to 3^L frames per pixel at level L in theory,
-// a tenth of a frame per pixel in the reference's scenes.
+// pixel; a deeper level starts with the same capacity — a QUARTER of it in launches of more than 16 M pixels (batches of frames) —
+// and is grown to what an overflowed frame reported (check_overflow): a frame can hold up to 3^L frames per pixel at level L in
+// theory, a tenth of a frame per pixel in the reference's scenes. (Round 3: every level as large as level 0 was 80 GB per context
+// with 32 frames of 1920 x 1080 in flight — a fourth context on one GPU ran out of memory; now 30 GB.)
 int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = false) {
     if (gi) ctx->want_gi = true;
     // one shard of level 0 receives the frames of every RTU_SHARDS-th 8x8 tile of the launch (ragged right /
@@ -916,8 +917,9 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     size_t want[RTU_MAX_LEVELS];
     size_t maxcap = cap_s0;
     bool fits = ctx->level_nsl == ctx->nsl && (!ctx->textured || ctx->lv[0].fuv) && (!ctx->want_gi || ctx->lv[0].famb);
+    const size_t cap_deep = cap_s0 * RTU_SHARDS > ((size_t)16 << 20) ? ((cap_s0 / 4 + 63) / 64) * 64 : cap_s0;
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
-        want[L] = L == 0 || ctx->want_cap_s[L] < cap_s0 ? cap_s0 : ctx->want_cap_s[L];
+        want[L] = L == 0 ? cap_s0 : std::max<size_t>(cap_deep, ctx->want_cap_s[L]);
         if (want[L] > maxcap) maxcap = want[L];
         fits = fits && ctx->lv[L].cap_s >= want[L];
     }

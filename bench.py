@@ -449,14 +449,17 @@ def main():
     if not sampled and world == 1 and B > 1:
         n1 = max(20, min(100, args.steps))
         settle(lambda: [launch([frame0], shard) for _ in range(5)])  # (the cut level of the tail kernel is learned per launch shape)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(n1):
-            launch([frame0], shard)
-        torch.cuda.synchronize()
-        el1 = time.perf_counter() - ts
+        els = []
+        for _ in range(5):  # (median of five runs of n1 frames: one run is a 7 - 37 ms sample, a host hiccup away from 15 % off)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(n1):
+                launch([frame0], shard)
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - ts)
+        el1 = float(np.median(els))
         ctx.frame_status()
-        single = {"frames_in_flight": 1, "frames": n1, "ms_per_frame": round(el1 / n1 * 1e3, 4),
+        single = {"frames_in_flight": 1, "frames": n1, "runs": len(els), "ms_per_frame": round(el1 / n1 * 1e3, 4),
                   "mrays_per_s": round(rays_of[0] * n1 / el1 / 1e6, 1)}
 
     if rank == 0:

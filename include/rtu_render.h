@@ -272,7 +272,9 @@ int  rtu_debug_node_bounds(RtuContext* ctx, int on);
  * stage-2 kernels of every tracing phase are launched at full size), 64 = the occluder lists of shadow rays only say "empty cell or
  * not" (every listed ray walks the BVH), 2048 = no Shade() call is settled without a frame record (every hit becomes a frame),
  * 8192 = no side mode (stage 2 of the primary phase in the launch stream, before the recursion levels, instead of beside them),
- * 16384 = both stage-2 kernels of every phase are launched whatever the last launch's list lengths said (outside side mode). */
+ * 16384 = both stage-2 kernels of every phase are launched whatever the last launch's list lengths said (outside side mode).
+ * 131072 (a wrong image; frames with collect_stats == 2 only) = stage 2 of the primary phase writes the work of each ray's BVH walk — two
+ * units per inner step, one per triangle test — over the pixel's red channel (tools/scratch/walk_units.py). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on

@@ -393,6 +393,7 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
                                               const uint32_t stride = 64, const float4* lds_nodes = nullptr) {
     const DevScene& s = a.scene;
     bool want = false;
+    unsigned walk_units = 0;  // touched-bytes mode: the work of this ray's BVH walk (two per inner step of the 4-wide tree, one per triangle test)
     Hit h;
     fresh_hit(h, RTU_BIGFLOAT);
     Ray ray;
@@ -498,7 +499,9 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         ray.dir = norm3(cp - ray.p);
         RTU_CNT(prim);
         bool hit = false;
+        const unsigned units0 = CNTD ? cnt.t_inner4 * 2u + cnt.t_tri : 0u;
         if (!(a.dbg & 4u)) hit = trace<STACK, STATS, !STATS, DEFER, COOP, TEXD, CNTD>(s, ray, false, h, stk, cnt, deferred, stride, lds_nodes, skip, rects);
+        if (CNTD) walk_units = cnt.t_inner4 * 2u + cnt.t_tri - units0;
         if (!deferred && leader) {
             if (!hit) {
                 f3 bg = background_sample<TEXD>(s, x, y);  // :145
@@ -542,6 +545,9 @@ __device__ __forceinline__ void primary_pixel(const KernelArgs& a, bool valid, i
         }
     }
     if (!(a.dbg & 8u)) append_root<TEX>(a, want, shard, info, h.p, h.N, pix, ray.dir, h.z, h.uvw, cnt, !DEFER && !STATS);
+    // (diagnostics, rtu_debug_flags 131072 in touched-bytes mode: the one-lane-per-ray stage 2 writes the walk's units over the pixel's red
+    // channel — the distribution of walk lengths, ray by ray: tools/scratch/walk_units.py. A WRONG image, like the other experiment bits.)
+    if (CNTD && !DEFER && !COOP && (a.dbg & 131072u) && valid) a.out[pix].x = (float)walk_units;
 }
 
 // stage 1: one 8x8 pixel tile per wavefront, four wavefronts per workgroup

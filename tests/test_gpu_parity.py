@@ -1332,6 +1332,51 @@ def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
         pkg.hip.rtu_device_free(ctx._h, d)
 
 
+def test_walk_units_diagnostic_touches_only_what_it_says(pkg, ctx, golden):
+    """rtu_debug_flags 131072 (include/rtu_render.h): in touched-bytes mode the one-lane-per-ray stage 2 of the primary phase writes the work
+    of each deferred ray's BVH walk over the pixel's RED channel — z, green and blue of every pixel and all of the other pixels stay the
+    image's; without touched-bytes mode the flag does nothing at all. The units are what the touched table counts: two per inner step of
+    the 4-wide tree and one per triangle test of k_primary2, less the entries its inline shading tests."""
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H, n = g.width, g.height, 4
+    d = pkg.hip.rtu_device_alloc(ctx._h, n * W * H * 16)
+    out = np.empty((n, H, W, 4), np.float32)
+
+    def render(stats):
+        fs = [pkg.frame_setup(scene.desc.camera, W, H, collect_stats=stats) for _ in range(n)]
+        for attempt in range(8):
+            ctx.render_frames_device(fs, d, None)
+            try:
+                ctx.frame_status()
+                break
+            except pkg.RtuError as e:
+                if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                    raise
+        assert pkg.hip.rtu_copy_to_host(ctx._h, out.ctypes.data, d, out.nbytes) == 0
+        return out.copy()
+    try:
+        pkg.hip.rtu_debug_flags(ctx._h, 8192)
+        ref = render(2)
+        assert sha256(ref[0][..., 3]) == g.meta["sha256_z_f32"]
+        pkg.hip.rtu_debug_flags(ctx._h, 8192 | 131072)
+        assert np.array_equal(render(0).view(np.uint32), ref.view(np.uint32))  # not touched-bytes mode: no effect
+        got = render(2)
+        t = ctx.touched(False)
+        assert np.array_equal(got[..., 1:].view(np.uint32), ref[..., 1:].view(np.uint32))
+        changed = got[0, ..., 0] != ref[0, ..., 0]
+        _, deferred = ctx.frame_counts()
+        assert 0.97 * deferred[0] / n <= changed.sum() <= deferred[0] / n  # (a unit count may coincide with the red it replaces)
+        units = got[0, ..., 0][changed]
+        assert units.min() >= 1 and units.max() < 1000 and np.all(units == np.round(units))
+        k2 = t["k_primary2"]
+        assert abs(n * units.sum() - (2 * k2["inner4"] + k2["tri_tests"])) <= 0.2 * n * units.sum()  # (+ the list entries of the inline shading)
+    finally:
+        pkg.hip.rtu_debug_flags(ctx._h, 0)
+        pkg.hip.rtu_device_free(ctx._h, d)
+
+
 def test_idle_cooperative_launches_dropped_and_a_wrong_hint_is_harmless(pkg, ctx, golden):
     """Round 3: a phase whose list was the one-lane-per-ray kernel's last time launches no (idle) cooperative kernel — its workgroups
     want a whole CU and stall the sequence beside another stream's kernels — and the one-lane-per-ray kernel takes the list WHATEVER

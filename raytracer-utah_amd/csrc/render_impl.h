@@ -851,15 +851,15 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L,
 
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
+__global__ void __launch_bounds__(RTU_COOP2_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
-    __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
+    __shared__ uint32_t s_stack[RTU_COOP2_GROUPS * RTU_STACK8];
     const NarrowGeom g = narrow_geom(a, ph);
     if (g.R != 8u) return;
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
-    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP_GROUPS;  // see k_primary2c
+    const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP2_GROUPS;  // see k_primary2c
     const uint32_t kmax = (g.nmax + groups - 1u) / groups;
     const uint32_t chunks = kmax * RTU_SHARDS;
     if (blockIdx.x >= chunks) return;
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(RTU_COOP_THREADS) k_trace2c(KernelArgs a, int 
         if (e >= ns) continue;
         const uint32_t id = a.defer_list[(size_t)shard * a.defer_cap_s + e];
         if (leader) RTU_BYTES(4u);
-        frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP_GROUPS, s_nodes);
+        frame_ray<RTU_STACK8, false, false, true, TEX>(a, L, sel, id >> 28, id & 0x0FFFFFFFu, s_stack + grp, cnt, leader, RTU_COOP2_GROUPS, s_nodes);
     }
     flush_touched<TEX>(a, cnt, RTU_TL_LEVEL0 + 4 * L + 1);
 }
@@ -1809,6 +1809,10 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
         return (n1 != 0u && n1 - 1u > 2u * (uint64_t)thr) ? dim3(16) : gridCoop;
     };
+    auto grid_coop2 = [&](int ph) {  // (k_trace2c: workgroups of half the size, twice as many)
+        const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
+        return (n1 != 0u && n1 - 1u > 2u * (uint64_t)thr) ? dim3(32) : dim3(2u * gridCoop.x);
+    };
     // The cooperative kernel of a phase whose list was beyond the threshold last time is not launched at all, and the one-lane-per-ray
     // kernel takes the list whatever its length turns out to be (`alone`; any choice renders the same image). Idle, that kernel costs
     // nothing in an EMPTY machine (launches overlap in the command processor: measured) — but its 1024-thread workgroups want a CU's
@@ -1878,7 +1882,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L, (k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, a, L, sel, ph);
             if (a.n_meshes) {
                 const bool nc = no_coop(ph);
-                if (!nc) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop(ph), dim3(RTU_COOP_THREADS), a, L, sel, ph);
+                if (!nc) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop2(ph), dim3(RTU_COOP2_THREADS), a, L, sel, ph);
                 RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph, nc ? 1 : 0);
             }
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);

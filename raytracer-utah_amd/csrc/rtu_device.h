@@ -229,15 +229,19 @@ struct LevelBuffers {
 // ~88 atomics/us on MI355X (32 400 tiles => ~370 us, measured), so every level's arrays
 // are split into RTU_SHARDS independent regions, each with its own counter; a wavefront
 // appends to the shard of its own index, which keeps the regions balanced.
-// LDS node area of the cooperative (8 lanes per ray, 1024 threads per workgroup) kernels:
-// the whole 160 KB of a CU minus the 128 per-ray traversal stacks.
+// The cooperative kernels (8 lanes per ray): k_primary2c is one 1024-thread workgroup per CU (128 rays), k_trace2c two 512-thread
+// workgroups per CU (64 rays each: measured, one frame alone: 47 / 28 / 30 instead of 55 / 35 / 35 us for levels 0 / 1 / 2 — a
+// launch lasts as long as its slowest workgroup, and halves finish sooner —, while k_primary2c's longer list prefers the full one:
+// 58 against 75 us). LDS node area of both: 64 KB, the top 256 nodes of the meshes' 8-wide trees in breadth-first order (the teapot's
+// whole tree is 230), beside the per-ray traversal stacks (32 / 16 KB): two of the smaller workgroups fit a CU's 160 KB.
 #define RTU_COOP_THREADS 1024
 #define RTU_COOP_GROUPS  (RTU_COOP_THREADS / 8)
-#define RTU_LDS_BYTES    163840
+#define RTU_COOP2_THREADS 512
+#define RTU_COOP2_GROUPS (RTU_COOP2_THREADS / 8)
 #define RTU_STACK8       64   // stack entries per ray of the cooperative walk (8-wide tree: up to 7 pushes per step;
                               // a ray that would need more is finished on the reference's tree, like an exact tie)
 #define RTU_REF8_EMPTY   0x0FFFFFFFu
-#define RTU_LDS_NODE_F4  ((RTU_LDS_BYTES - RTU_COOP_GROUPS * RTU_STACK8 * 4) / 16)
+#define RTU_LDS_NODE_F4  4096
 
 #define RTU_MAX_COVER 8       // mesh nodes that get a coverage mask for primary rays
 #define RTU_SHARDS 64

@@ -650,12 +650,12 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_primary2(KernelArgs a, int 
 // stage 2 of the primary phase, short lists: COOPERATIVE — eight lanes per pixel
 // (mesh_hit_coop), 128 pixels per 1024-thread workgroup, the top of the BVH in LDS.
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a) {
+__global__ void __launch_bounds__(RTU_COOP_THREADS) k_primary2c(KernelArgs a, int alone) {
     const Stamp stamp(a, RTU_TL_PRIMARY2C);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
     __shared__ uint32_t s_stack[RTU_COOP_GROUPS * RTU_STACK8];
     const NarrowGeom g = narrow_geom(a, 0);
-    if (g.R != 8u) return;
+    if (g.R != 8u && !alone) return;  // long list: k_primary2 takes it (alone: it was not launched — launch_all)
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
     // A very short list is pure latency: one wavefront per SIMD (32 rays per workgroup) so that
@@ -851,12 +851,12 @@ __global__ void __launch_bounds__(64) RTU_OCC_WALK k_trace2(KernelArgs a, int L,
 
 // stage 2, short lists: cooperative, eight lanes per ray (see k_primary2c)
 template <int STACK, int TEX>
-__global__ void __launch_bounds__(RTU_COOP2_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph) {
+__global__ void __launch_bounds__(RTU_COOP2_THREADS) k_trace2c(KernelArgs a, int L, int sel, int ph, int alone) {
     const Stamp stamp(a, RTU_TL_LEVEL0 + 4 * L + 1);
     __shared__ float4 s_nodes[RTU_LDS_NODE_F4];
     __shared__ uint32_t s_stack[RTU_COOP2_GROUPS * RTU_STACK8];
     const NarrowGeom g = narrow_geom(a, ph);
-    if (g.R != 8u) return;
+    if (g.R != 8u && !alone) return;  // long list: k_trace2 takes it (alone: it was not launched — launch_all)
     const uint32_t grp = threadIdx.x >> 3;
     const bool leader = (threadIdx.x & 7u) == 0;
     const uint32_t groups = g.sum < 12288u ? 32u : (uint32_t)RTU_COOP2_GROUPS;  // see k_primary2c
@@ -1823,6 +1823,13 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
         return (a.side || !(a.dbg & 16384u)) && n1 != 0u && n1 - 1u > (uint64_t)thr;
     };
+    // ... and the other way round: a phase whose list was below seven eighths of the threshold last time launches the cooperative kernel ONLY,
+    // which then takes the list whatever its length (an idle launch of the one-lane-per-ray kernel is 1.3 us of kernel and a microsecond of
+    // gap: four of them are 3 % of a single frame).
+    auto no_lane = [&](int ph) {
+        const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
+        return !(a.dbg & 16384u) && !a.side && n1 != 0u && (uint64_t)(n1 - 1u) <= (uint64_t)thr - thr / 8u;
+    };
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups
     const uint32_t blocksP = (n_tiles + 3) / 4;
@@ -1861,9 +1868,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             }
             (void)hipEventRecord((hipEvent_t)a.aux_ev1, aux);
         } else if (a.n_meshes) {  // without meshes nothing is ever deferred
-            const bool nc = no_coop(0);
-            if (!nc) RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a);
-            RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, nc ? 1 : 0);
+            const bool nc = no_coop(0), nl = no_lane(0);
+            if (!nc) RTU_LAUNCH(RTU_TL_PRIMARY2C, (k_primary2c<STACK, TEX>), grid_coop(0), dim3(RTU_COOP_THREADS), a, nl ? 1 : 0);
+            if (!nl) RTU_LAUNCH(RTU_TL_PRIMARY2, (k_primary2<STACK, TEX>), grid_lane(0, gridN), block, a, nc ? 1 : 0);
         }
     }
     if (mode == RTU_LAUNCH_CHAIN) return (int)hipGetLastError();
@@ -1881,9 +1888,9 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
             const int sel = (int)(SEL_SHADOW | SEL_MAIN | SEL_A | SEL_C);
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L, (k_trace<STACK, false, TEX>), L == 0 ? gridT : gridS, block, a, L, sel, ph);
             if (a.n_meshes) {
-                const bool nc = no_coop(ph);
-                if (!nc) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop2(ph), dim3(RTU_COOP2_THREADS), a, L, sel, ph);
-                RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph, nc ? 1 : 0);
+                const bool nc = no_coop(ph), nl = no_lane(ph);
+                if (!nc) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 1, (k_trace2c<STACK, TEX>), grid_coop2(ph), dim3(RTU_COOP2_THREADS), a, L, sel, ph, nl ? 1 : 0);
+                if (!nl) RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 2, (k_trace2<STACK, TEX>), grid_lane(ph, L == 0 ? gridN : gridS), block, a, L, sel, ph, nc ? 1 : 0);
             }
             RTU_LAUNCH(RTU_TL_LEVEL0 + 4 * L + 3, (k_consume<false, TEX>), L == 0 ? gridF0 : gridF, block, a, L);
         }

@@ -46,6 +46,7 @@ struct RtuContext {
     uint32_t  defer_cap0_s = 0;
     LevelBuffers lv_side[RTU_MAX_LEVELS] = {};
     std::map<uint64_t, bool> side_off;       // launch shapes whose stage 2 made more frames than the side arrays take: no side mode for them
+    std::map<uint64_t, uint32_t> occ_hints;   // ... and how many 8x8 tiles had anything in them (k_tile_occ): the grid of k_primary
     std::map<uint64_t, uint64_t> side_frames; // ... and how many level-0 frames stage 2 of the primary phase made in the last launch of a shape
     bool     last_side = false;
     bool     mesh_hits_childless = false;    // no mesh node's material reflects or refracts: a mesh hit's Shade() call is settled by the lane that found it
@@ -1167,6 +1168,9 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
         RTU_HIP(ctx, hipMemsetAsync(ctx->fcnt_side, 0, offsetof(FrameCounters, overflow), stream));  // (ahead of k_primary, which fills its defer counters)
         ctx->last_side = true;
     }
+    // k_primary's grid (render_impl.h launch_all): few, long-lived workgroups when the last launch of this shape found most tiles empty
+    a.pgrid = 32768u;
+    if (a.occ && !(ctx->dbg & 512u) && ctx->occ_hints.count(tail_key) && (uint64_t)ctx->occ_hints[tail_key] * 3u < (uint64_t)n_tiles) a.pgrid = 4096u;
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
@@ -1260,6 +1264,11 @@ int check_overflow(RtuContext* ctx, bool* overflow) {
                 fprintf(stderr, "[side] deferred pixels %llu, side frames per level %llu %llu %llu %llu %llu %llu, failed %d\n", d0, f[0], f[1], f[2], f[3], f[4], f[5], (int)side_failed);
             }
         }
+    }
+    {
+        uint64_t occ = 0;
+        for (int s = 0; s < RTU_SHARDS; s++) occ += h.occ_tiles[s * RTU_CSTRIDE];
+        if (!ctx->last_stats) ctx->occ_hints[ctx->last_tail_key] = (uint32_t)(occ < 0xFFFFFFFFull ? occ : 0xFFFFFFFFull);
     }
     if (!ctx->last_side && !ctx->last_stats) ctx->side_frames[ctx->last_tail_key] = stage2_total(h);  // (the fast variant without side mode: counted in the main counters)
     *overflow = h.overflow != 0 || h.tail_declined != 0 || side_failed;
@@ -1724,6 +1733,7 @@ int rtu_upload_scene(RtuContext* ctx, const RtuSceneDesc* s) {
     }
     ctx->side_off.clear();
     ctx->side_frames.clear();
+    ctx->occ_hints.clear();
     ctx->any_recursive_material = false;
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const RtuMaterial& mm = s->materials[i];

@@ -264,6 +264,7 @@ struct FrameCounters {
     uint32_t n_pending[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];    // frames waiting for children (fpend)
     uint32_t n_lmain[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];      // entries of lmain / lrefl
     uint32_t n_lrefl[RTU_MAX_LEVELS][RTU_SHARDS * RTU_CSTRIDE];
+    uint32_t occ_tiles[RTU_SHARDS * RTU_CSTRIDE];      // 8x8 tiles with anything in them (k_tile_occ), per shard of counters: what the host sizes k_primary's grid by
     uint32_t stage2_frames[RTU_SHARDS * RTU_CSTRIDE];  // level-0 frames appended by stage 2 of the primary phase, per shard like the lists (what the host decides side mode by; zeroed per launch)
     uint32_t overflow;   // a level ran out of capacity: the frame must be re-rendered with more (sticky: rtu_frame_status)
     uint32_t tail_declined;  // k_tail found more frames at its cut level than it takes (RTU_TAIL_DECLINE): it evaluated nothing, the frame
@@ -300,6 +301,7 @@ struct KernelArgs {
     FrameCounters* fcnt0;
     uint32_t*    defer_list0;       // [RTU_SHARDS * defer_cap0_s] pixels waiting for stage 2 of the primary phase
     uint32_t     defer_cap0_s, side;  // side: 1 in side mode
+    uint32_t     pgrid, pad_pg;       // workgroups of k_primary at most (HOST ONLY: launch_all)
     void*        aux_stream;        // HOST ONLY (launch_all): the helper stream and two events of side mode
     void*        aux_ev0;
     void*        aux_ev1;

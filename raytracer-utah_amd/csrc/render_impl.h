@@ -1829,7 +1829,7 @@ int launch_all(const KernelArgs& a, uint32_t n_tiles, bool stats, hipStream_t st
     // gap: four of them are 3 % of a single frame).
     auto no_lane = [&](int ph) {
         const uint32_t n1 = ph < 8 ? a.list_n[ph] : 0u;
-        return !(a.dbg & 16384u) && !a.side && n1 != 0u && (uint64_t)(n1 - 1u) <= (uint64_t)thr - thr / 8u;
+        return !(a.dbg & 16384u) && n1 != 0u && (uint64_t)(n1 - 1u) <= (uint64_t)thr - thr / 8u;
     };
     if (n_tiles == 0) return (int)hipSuccess;
     // k_primary: one tile per wavefront for the counting variant; the fast variant strides its tiles over at most 32768 workgroups

@@ -244,6 +244,9 @@ def main():
         tstreams.append(torch.cuda.Stream(device=dev))
         shards.append(torch.zeros_like(shards[0]))
 
+    for cx in ctxs:  # (a hint: every context sizes its long-running kernels for its share of the machine)
+        pkg.hip.rtu_set_sequences_in_flight(cx._h, C)
+
     def launch(frs, buf, k=0):
         if len(frs) == 1:
             ctxs[k].render_device(frs[0], buf.data_ptr(), tstreams[k].cuda_stream)
@@ -448,6 +451,7 @@ def main():
     single = None
     if not sampled and world == 1 and B > 1:
         n1 = max(20, min(100, args.steps))
+        pkg.hip.rtu_set_sequences_in_flight(ctx._h, 1)  # (one frame at a time on one context)
         settle(lambda: [launch([frame0], shard) for _ in range(5)])  # (the cut level of the tail kernel is learned per launch shape)
         els = []
         for _ in range(5):  # (median of five runs of n1 frames: one run is a 7 - 37 ms sample, a host hiccup away from 15 % off)

@@ -276,6 +276,11 @@ int  rtu_debug_node_bounds(RtuContext* ctx, int on);
  * 131072 (a wrong image; frames with collect_stats == 2 only) = stage 2 of the primary phase writes the work of each ray's BVH walk — two
  * units per inner step, one per triangle test — over the pixel's red channel (tools/scratch/walk_units.py). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
+/* A hint, never needed for correctness: how many launch sequences the caller keeps in flight on this GPU at once, over all of its
+ * contexts together (bench.py alternates its batches over three contexts: 3). A context then sizes the grid of its long-running
+ * primary kernel for its share of the machine instead of all of it (measured, three sequences in flight: 58.9 -> 61.1 Grays/s).
+ * Default 1. Any value renders the same images. */
+int  rtu_set_sequences_in_flight(RtuContext* ctx, int n);
 
 /* Test hook: let the walks of the fast trees use at most `entries` stack entries from the next frame on
  * (until the next upload), so that tests can exercise the overflow path — a ray whose walk would

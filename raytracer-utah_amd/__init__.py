@@ -142,7 +142,7 @@ def _sig(lib, name, restype, *argtypes):
 # ---- rtu_render.h ----------------------------------------------------------
 HIP_SYMBOLS = ["rtu_device_count", "rtu_error_string", "rtu_create_context", "rtu_destroy_context", "rtu_last_error",
                "rtu_upload_scene", "rtu_validate_scene", "rtu_frame_setup", "rtu_shard_rows", "rtu_shard_max_rows", "rtu_shard_global_row",
-               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_light_list", "rtu_debug_light_list_free", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_get_touched_launches", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
+               "rtu_render_frame_device", "rtu_render_frames_device", "rtu_pack_image_device", "rtu_minmax_z_device", "rtu_pack_output_device", "rtu_render_frame", "rtu_frame_status", "rtu_render_timeline", "rtu_frame_counts", "rtu_timeline_exits", "rtu_mesh_info", "rtu_light_list_info", "rtu_debug_light_list", "rtu_debug_light_list_free", "rtu_debug_walk_stack_limit", "rtu_debug_node_bounds", "rtu_debug_flags", "rtu_set_sequences_in_flight", "rtu_debug_tail_from", "rtu_get_stats", "rtu_get_touched", "rtu_get_touched_launches", "rtu_touched_bytes", "rtu_kernel_slot_name", "rtu_probe_kernel", "rtu_probe_read", "rtu_time_render", "rtu_selftest_division", "rtu_selftest_primitives", "rtu_context_stream", "rtu_context_device", "rtu_context_sync", "rtu_host_alloc_pinned", "rtu_host_free_pinned", "rtu_copy_to_host_async", "rtu_device_alloc",
                "rtu_device_free", "rtu_copy_to_host", "rtu_device_info", "rtu_set_cancel_flag", "rtu_create_context_multi", "rtu_destroy_context_multi",
                "rtu_multi_size", "rtu_multi_context", "rtu_multi_last_error", "rtu_multi_upload_scene", "rtu_multi_render_frame", "rtu_multi_gather_kind"]
 _sig(hip, "rtu_device_count", _I)
@@ -172,6 +172,7 @@ _sig(hip, "rtu_probe_read", _I, _P, ctypes.POINTER(ctypes.c_float), ctypes.POINT
 _sig(hip, "rtu_debug_walk_stack_limit", _I, _P, ctypes.c_uint32)
 _sig(hip, "rtu_debug_node_bounds", _I, _P, _I)
 _sig(hip, "rtu_debug_flags", _I, _P, ctypes.c_uint32)
+_sig(hip, "rtu_set_sequences_in_flight", _I, _P, _I)
 _sig(hip, "rtu_debug_tail_from", _I, _P, _I)
 _sig(hip, "rtu_timeline_exits", _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double))
 _sig(hip, "rtu_mesh_info", _I, _P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32))

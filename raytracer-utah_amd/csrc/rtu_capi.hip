@@ -42,6 +42,7 @@ struct RtuContext {
     uint32_t* defer_list = nullptr;
     uint32_t  defer_cap_s = 0;
     FrameCounters* fcnt_side = nullptr;      // side mode: counters of the primary phase's defer list and of the side level arrays
+    int sequences_in_flight = 1;             // rtu_set_sequences_in_flight: launch sequences the caller keeps in flight on this GPU (all its contexts together)
     uint32_t* defer_list0 = nullptr;         // the primary phase's own defer list
     uint32_t  defer_cap0_s = 0;
     LevelBuffers lv_side[RTU_MAX_LEVELS] = {};
@@ -1170,7 +1171,8 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     }
     // k_primary's grid (render_impl.h launch_all): few, long-lived workgroups when the last launch of this shape found most tiles empty
     a.pgrid = 32768u;
-    if (a.occ && !(ctx->dbg & 512u) && ctx->occ_hints.count(tail_key) && (uint64_t)ctx->occ_hints[tail_key] * 3u < (uint64_t)n_tiles) a.pgrid = 4096u;
+    if (a.occ && !(ctx->dbg & 512u) && ctx->occ_hints.count(tail_key) && (uint64_t)ctx->occ_hints[tail_key] * 3u < (uint64_t)n_tiles)
+        a.pgrid = ctx->sequences_in_flight >= 3 ? 1024u : ctx->sequences_in_flight == 2 ? 2048u : 4096u;  // (its share of the machine: rtu_set_sequences_in_flight)
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);
@@ -2107,6 +2109,12 @@ int rtu_set_cancel_flag(RtuContext* ctx, const volatile int* flag) {
 int rtu_debug_tail_from(RtuContext* ctx, int level) {
     if (!ctx || level < 1 || level > RTU_MAX_LEVELS) return RTU_ERR_ARG;
     ctx->tail_hint = level;
+    return RTU_OK;
+}
+
+int rtu_set_sequences_in_flight(RtuContext* ctx, int n) {
+    if (!ctx || n < 1) return RTU_ERR_ARG;
+    ctx->sequences_in_flight = n;
     return RTU_OK;
 }
 

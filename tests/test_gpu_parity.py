@@ -1332,6 +1332,47 @@ def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
         pkg.hip.rtu_device_free(ctx._h, d)
 
 
+def test_grid_hints_change_no_pixel(pkg, ctx, golden):
+    """k_primary's grid follows two hints — the occupied tiles the last launch of the shape counted (k_tile_occ) and the number of launch
+    sequences the caller says it keeps in flight (rtu_set_sequences_in_flight) —: 32768 / 4096 / 2048 / 1024 workgroups, tiles strided
+    over them. Every combination renders the single frames' images, bit for bit; a bad argument is an error code."""
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H, n = g.width, g.height, 3
+    cams = []
+    for i in range(n):
+        cam = type(scene.desc.camera).from_buffer_copy(scene.desc.camera)
+        cam.pos[0] += 0.4 * i
+        cams.append(cam)
+    singles = [ctx.render(pkg.frame_setup(c, W, H))[0] for c in cams]
+    assert sha256(singles[0][..., 3]) == g.meta["sha256_z_f32"]
+    d = pkg.hip.rtu_device_alloc(ctx._h, n * W * H * 16)
+    got = np.empty((n, H, W, 4), np.float32)
+    try:
+        assert pkg.hip.rtu_set_sequences_in_flight(ctx._h, 0) == pkg.RTU_ERR_ARG
+        for seqs in (1, 2, 3, 7):
+            assert pkg.hip.rtu_set_sequences_in_flight(ctx._h, seqs) == 0
+            for rep in range(2):  # (the second launch of the shape knows the first's tile count)
+                fs = [pkg.frame_setup(c, W, H) for c in cams]
+                for attempt in range(8):
+                    ctx.render_frames_device(fs, d, None)
+                    try:
+                        ctx.frame_status()
+                        break
+                    except pkg.RtuError as e:
+                        if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                            raise
+                assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+                for i in range(n):
+                    assert np.array_equal(got[i].view(np.uint32), singles[i].view(np.uint32)), "sequences %d, launch %d: frame %d differs" % (seqs, rep, i)
+            out = ctx.render(pkg.frame_setup(cams[1], W, H))[0]
+            assert np.array_equal(out.view(np.uint32), singles[1].view(np.uint32))
+    finally:
+        pkg.hip.rtu_set_sequences_in_flight(ctx._h, 1)
+        pkg.hip.rtu_device_free(ctx._h, d)
+
+
 def test_walk_units_diagnostic_touches_only_what_it_says(pkg, ctx, golden):
     """rtu_debug_flags 131072 (include/rtu_render.h): in touched-bytes mode the one-lane-per-ray stage 2 of the primary phase writes the work
     of each deferred ray's BVH walk over the pixel's RED channel — z, green and blue of every pixel and all of the other pixels stay the

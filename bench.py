@@ -122,8 +122,8 @@ def main():
     ap.add_argument("--rays-per-frame", type=int, default=0,
                     help="diagnostic only: skip the (slow, untimed) counting pass that counts the reference's rays per frame and use this number instead — "
                          "for profiler runs of sampled frames, where the counting variant would drown the timed kernels in the trace")
-    ap.add_argument("--contexts", type=int, default=3,
-                    help="N=1: launch sequences alternate over this many contexts, each on a stream of its own (default 3; measured 1 / 2 / 3 / 4: 47.7 / 55.4 / 57.5 / 55.0 Grays/s): the latency-bound recursion "
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="N=1: launch sequences alternate over this many contexts, each on a stream of its own (default 2; measured 1 / 2 / 3: 49.4 / 62.5 / 60.5 Grays/s): the latency-bound recursion "
                          "levels of one sequence overlap the primary kernels of the next. Only when the timed region holds at least that many full "
                          "batches (the driver's --steps 20 is one batch: one context)")
     ap.add_argument("--same-camera", action="store_true", help="diagnostic only: every frame of a batch from the golden camera (no turntable)")

@@ -277,8 +277,8 @@ int  rtu_debug_node_bounds(RtuContext* ctx, int on);
  * units per inner step, one per triangle test — over the pixel's red channel (tools/scratch/walk_units.py). */
 int  rtu_debug_flags(RtuContext* ctx, uint32_t bits);
 /* A hint, never needed for correctness: how many launch sequences the caller keeps in flight on this GPU at once, over all of its
- * contexts together (bench.py alternates its batches over three contexts: 3). A context then sizes the grid of its long-running
- * primary kernel for its share of the machine instead of all of it (measured, three sequences in flight: 58.9 -> 61.1 Grays/s).
+ * contexts together (bench.py alternates its batches over two contexts: 2). A context then sizes the grid of its long-running
+ * primary kernel for its share of the machine instead of all of it (measured, two sequences in flight: 59.4 -> 62.5 Grays/s).
  * Default 1. Any value renders the same images. */
 int  rtu_set_sequences_in_flight(RtuContext* ctx, int n);
 

@@ -1172,7 +1172,10 @@ int launch(RtuContext* ctx, const RtuFrameDesc* frame, float4* d_out, hipStream_
     // k_primary's grid (render_impl.h launch_all): few, long-lived workgroups when the last launch of this shape found most tiles empty
     a.pgrid = 32768u;
     if (a.occ && !(ctx->dbg & 512u) && ctx->occ_hints.count(tail_key) && (uint64_t)ctx->occ_hints[tail_key] * 3u < (uint64_t)n_tiles)
-        a.pgrid = ctx->sequences_in_flight >= 3 ? 1024u : ctx->sequences_in_flight == 2 ? 2048u : 4096u;  // (its share of the machine: rtu_set_sequences_in_flight)
+        // (alone: four rounds of resident wavefronts balance themselves; beside another sequence — rtu_set_sequences_in_flight —: ONE resident
+        // set, which the other sequence's kernels fill in around. Two sequences in flight: 2048 / 1536 / 1024 / 768 workgroups: 59.4 / 61.4 /
+        // 62.5 / 61.4 Grays/s; three: 60 - 61 whatever the grid.)
+        a.pgrid = ctx->sequences_in_flight >= 2 ? 1024u : 4096u;
     ctx->last_tail_from = a.tail_from;
     ctx->last_stats = stats == 1;
     memcpy(a.shadow_light, ctx->shadow_light, sizeof a.shadow_light);

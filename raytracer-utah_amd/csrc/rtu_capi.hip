@@ -929,6 +929,17 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     size_t dcap_s = maxcap * (ctx->nsl + 3);
     if (ctx->want_defer_s > dcap_s) dcap_s = ctx->want_defer_s;
     if (fits && ctx->defer_cap_s >= dcap_s && ctx->defer_list0 && ctx->defer_cap0_s >= cap_s0) return RTU_OK;
+    // GROW ONLY: a caller that alternates launch shapes (a batch of 24 frames, then the last 8 of its run: the smaller one wants MORE at
+    // the deep levels — it is below the quarter rule's 16 M pixels — and less at level 0) must not make the arrays swing between the two
+    // (found as a 2.4 s stall per timed region: every launch freed and allocated 20 GB). Every capacity is the larger of what it was and
+    // what is wanted now.
+    size_t cap_s0_alloc = cap_s0 > ctx->defer_cap0_s ? cap_s0 : ctx->defer_cap0_s;
+    for (int L = 0; L < RTU_MAX_LEVELS; L++) {
+        if (ctx->lv[L].cap_s > want[L]) want[L] = ctx->lv[L].cap_s;
+        if (want[L] > maxcap) maxcap = want[L];
+    }
+    if (maxcap * (ctx->nsl + 3) > dcap_s) dcap_s = maxcap * (ctx->nsl + 3);
+    if (ctx->defer_cap_s > dcap_s) dcap_s = ctx->defer_cap_s;
     free_levels(ctx);
     int rc;
     size_t total = 0;
@@ -960,8 +971,8 @@ int ensure_levels(RtuContext* ctx, uint32_t pixels, uint32_t n_tiles, bool gi = 
     ctx->defer_cap_s = (uint32_t)dcap_s;
     // the primary phase's own defer list (at most every pixel of the launch) and the side set of level arrays (rtu_device.h
     // KernelArgs::fcnt0): small — a k_tail launch refuses more than RTU_TAIL_DECLINE frames anyway
-    if ((rc = alloc_level(ctx, &ctx->defer_list0, cap_s0 * RTU_SHARDS)) != RTU_OK) return rc;
-    ctx->defer_cap0_s = (uint32_t)cap_s0;
+    if ((rc = alloc_level(ctx, &ctx->defer_list0, cap_s0_alloc * RTU_SHARDS)) != RTU_OK) return rc;
+    ctx->defer_cap0_s = (uint32_t)cap_s0_alloc;
     for (int L = 0; L < RTU_MAX_LEVELS; L++) {
         LevelBuffers& lv = ctx->lv_side[L];
         const size_t cap_s = 256, cap = cap_s * RTU_SHARDS;

@@ -1332,6 +1332,47 @@ def test_childless_shade_calls_settled_without_a_frame(pkg, ctx, golden, tag):
         pkg.hip.rtu_device_free(ctx._h, d)
 
 
+def test_alternating_launch_shapes_do_not_reallocate(pkg, ctx, golden):
+    """A caller that alternates launch shapes — a run of batches whose last one is shorter — must not make the frame arrays swing between
+    the shapes' wishes: the smaller batch (below the 16 M pixels from which deeper levels start at a quarter of level 0) wants MORE at the
+    deep levels and less at level 0 than the larger one. The arrays only grow (ensure_levels); found as a 2.4 s stall per timed region of
+    `bench.py --frames-in-flight 24` (every launch freed and allocated 20 GB). Timed with two orders of magnitude to spare."""
+    import time
+    g = golden("teapot2_1080")
+    scene = g.scene(pkg)
+    ctx.upload(scene)
+    W, H = g.width, g.height
+    big, small = 9, 8  # 18.7 M pixels (quarter rule) and 16.6 M (not)
+    d = pkg.hip.rtu_device_alloc(ctx._h, big * W * H * 16)
+    single = ctx.render(pkg.frame_setup(scene.desc.camera, W, H))[0]
+
+    def launch(n):
+        fs = [pkg.frame_setup(scene.desc.camera, W, H) for _ in range(n)]
+        for attempt in range(8):
+            ctx.render_frames_device(fs, d, None)
+            try:
+                ctx.frame_status()
+                return
+            except pkg.RtuError as e:
+                if e.code != pkg.RTU_ERR_CAPACITY or attempt == 7:
+                    raise
+    try:
+        for _ in range(2):
+            launch(big)
+            launch(small)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            launch(big)
+            launch(small)
+        el = time.perf_counter() - t0
+        assert el < 0.6, "twelve launches took %.2f s: the frame arrays are being reallocated" % el
+        got = np.empty((small, H, W, 4), np.float32)
+        assert pkg.hip.rtu_copy_to_host(ctx._h, got.ctypes.data, d, got.nbytes) == 0
+        assert np.array_equal(got[small - 1].view(np.uint32), single.view(np.uint32))
+    finally:
+        pkg.hip.rtu_device_free(ctx._h, d)
+
+
 def test_grid_hints_change_no_pixel(pkg, ctx, golden):
     """k_primary's grid follows two hints — the occupied tiles the last launch of the shape counted (k_tile_occ) and the number of launch
     sequences the caller says it keeps in flight (rtu_set_sequences_in_flight) —: 32768 / 4096 / 2048 / 1024 workgroups, tiles strided
